@@ -1,0 +1,350 @@
+// quoridor_core.hpp -- bitboard Quoridor rules, shared by every HIP kernel (and by the host-side
+// self-check build under tests/hostcheck, so the logic tested on CPU is the logic run on gfx950).
+//
+// Contract reproduced (bit-exact): /root/reference/game_logic.py
+//   State fields            :25-40     is_lose/is_draw :43-54    legal_actions      :103-117
+//   legal_actions_pos       :120-192   legal_actions_wall :195-357 (can_place_wall :199-223,
+//   is_goal_possibly_blocked :227-307, bfs :309-324, can_reach_goal :325-348)
+//   rotate_walls/next       :359-391
+//
+// Formulation (NOT the reference's): tiles are an N*N-bit board (two u64), wall slots a 64-bit
+// mask per orientation.  "Blocked" masks per direction are built once per state by spreading the
+// slot masks (stride N-1) onto the tile grid (stride N); reachability is an iterated 4-direction
+// shift-and-mask flood fill.  The reference's BFS expands with legal_actions_pos, i.e. the other
+// pawn is an obstacle that can only be jumped (game_logic.py:174-188, :319); that is folded in as
+// (a) the obstacle tile is never entered, (b) for each of its <=4 neighbours p with an open edge
+// p->obstacle, reaching p also reaches the jump targets J_d.  The enemy's search runs in the
+// mover's frame (start/goal/obstacle rotated by 180 degrees instead of rotating the walls,
+// which is reachability-equivalent to game_logic.py:344-345).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define QHD __host__ __device__ __forceinline__
+#else
+#define QHD inline
+#endif
+
+namespace aqg {
+
+// ---------------------------------------------------------------------------------------------
+// state72: the byte record at the C-ABI boundary == State.to_array() flattened + plies + N.
+//   [0] player pos [1] player walls [2] enemy pos [3] enemy walls [4..67] walls[64]
+//   [68..69] plies (u16 LE) [70] N [71] 0
+// QState: the 24-byte register/HBM form used inside kernels and tree pools.
+// ---------------------------------------------------------------------------------------------
+constexpr int STATE72 = 72;
+constexpr int MAX_LEGAL = 136;  // >= 5 pawn moves + 128 walls, multiple of 8
+
+struct QState {
+    uint64_t hw;     // bit i: walls[i] == 1 (horizontal), mover's frame
+    uint64_t vw;     // bit i: walls[i] == 2 (vertical)
+    uint8_t ppos;    // player[0], player's own frame
+    uint8_t pwl;     // player[1]
+    uint8_t epos;    // enemy[0], ENEMY's own frame (game_logic.py:20-21)
+    uint8_t ewl;     // enemy[1]
+    uint16_t plies;  // plies_played
+    uint16_t pad;
+};
+static_assert(sizeof(QState) == 24, "QState must be 24 bytes");
+
+QHD QState unpack72(const uint8_t* r) {
+    QState s;
+    uint64_t h = 0, v = 0;
+    for (int i = 0; i < 64; ++i) {
+        uint8_t w = r[4 + i];
+        h |= (uint64_t)(w == 1) << i;
+        v |= (uint64_t)(w == 2) << i;
+    }
+    s.hw = h; s.vw = v;
+    s.ppos = r[0]; s.pwl = r[1]; s.epos = r[2]; s.ewl = r[3];
+    s.plies = (uint16_t)(r[68] | (r[69] << 8));
+    s.pad = 0;
+    return s;
+}
+
+QHD void pack72(const QState& s, int N, uint8_t* r) {
+    r[0] = s.ppos; r[1] = s.pwl; r[2] = s.epos; r[3] = s.ewl;
+    for (int i = 0; i < 64; ++i) r[4 + i] = (uint8_t)(((s.hw >> i) & 1) | (((s.vw >> i) & 1) << 1));
+    r[68] = (uint8_t)(s.plies & 0xff); r[69] = (uint8_t)(s.plies >> 8);
+    r[70] = (uint8_t)N; r[71] = 0;
+}
+
+QHD uint64_t brev64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brevll(x);
+#else
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0f0f0f0f0f0f0f0full) | ((x & 0x0f0f0f0f0f0f0f0full) << 4);
+    x = ((x >> 8) & 0x00ff00ff00ff00ffull) | ((x & 0x00ff00ff00ff00ffull) << 8);
+    x = ((x >> 16) & 0x0000ffff0000ffffull) | ((x & 0x0000ffff0000ffffull) << 16);
+    return (x >> 32) | (x << 32);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// 128-bit tile board
+// ---------------------------------------------------------------------------------------------
+struct BB {
+    uint64_t lo, hi;
+};
+QHD BB bb(uint64_t lo, uint64_t hi) { BB r; r.lo = lo; r.hi = hi; return r; }
+QHD BB bb_bit(int t) { return t < 64 ? bb(1ull << t, 0) : bb(0, 1ull << (t - 64)); }
+QHD BB operator|(BB a, BB b) { return bb(a.lo | b.lo, a.hi | b.hi); }
+QHD BB operator&(BB a, BB b) { return bb(a.lo & b.lo, a.hi & b.hi); }
+QHD BB operator~(BB a) { return bb(~a.lo, ~a.hi); }
+QHD bool bb_any(BB a) { return (a.lo | a.hi) != 0; }
+QHD bool bb_eq(BB a, BB b) { return a.lo == b.lo && a.hi == b.hi; }
+QHD bool bb_test(BB a, int t) { return t < 64 ? ((a.lo >> t) & 1) : ((a.hi >> (t - 64)) & 1); }
+template <int K> QHD BB bb_shl(BB a) {  // 0 < K < 64
+    return bb(a.lo << K, (a.hi << K) | (a.lo >> (64 - K)));
+}
+template <int K> QHD BB bb_shr(BB a) {
+    return bb((a.lo >> K) | (a.hi << (64 - K)), a.hi >> K);
+}
+
+template <int N> struct Geo {
+    static constexpr int V = N * N;          // tiles
+    static constexpr int S = N - 1;          // wall slots per row
+    static constexpr int NW = S * S;         // wall slots
+    static constexpr int A = V + 2 * NW;     // actions (209 at 9x9)
+    static_assert(N % 2 == 1 && N >= 3 && N <= 9, "odd board size 3..9 (game_logic.py:28-29)");
+};
+
+// constant tile masks ------------------------------------------------------------------------
+template <int N> QHD BB mask_all() {
+    constexpr int V = N * N;
+    if constexpr (V > 64) return bb(~0ull, (1ull << (V - 64)) - 1);
+    else return bb((1ull << V) - 1, 0);
+}
+template <int N> QHD BB mask_row(int x) {  // all tiles of row x
+    BB r = bb(0, 0);
+    for (int y = 0; y < N; ++y) r = r | bb_bit(x * N + y);
+    return r;
+}
+template <int N> QHD BB mask_col(int y) {
+    BB r = bb(0, 0);
+    for (int x = 0; x < N; ++x) r = r | bb_bit(x * N + y);
+    return r;
+}
+
+// per-direction "a move from this tile in direction d stays in-board and crosses no wall"
+struct Open {
+    BB U, D, L, R;
+};
+
+// spread a 64-bit slot mask (row stride S) onto the tile grid (row stride N): slot (sx,sy) -> tile (sx,sy)
+template <int N> QHD BB spread_slots(uint64_t m) {
+    constexpr int S = N - 1;
+    BB r = bb(0, 0);
+#pragma unroll
+    for (int sx = 0; sx < S; ++sx) {
+        uint64_t row = (m >> (S * sx)) & ((1ull << S) - 1);
+        int off = N * sx;
+        if (off < 64) {
+            r.lo |= row << off;
+            if (off + S > 64) r.hi |= row >> (64 - off);
+        } else {
+            r.hi |= row << (off - 64);
+        }
+    }
+    return r;
+}
+
+// game_logic.py:145-167 (is_wall_blocking) for every tile at once.
+//   H wall at slot (sx,sy): blocks DOWN from tiles (sx,sy),(sx,sy+1) and UP from (sx+1,sy),(sx+1,sy+1)
+//   V wall at slot (sx,sy): blocks RIGHT from (sx,sy),(sx+1,sy) and LEFT from (sx,sy+1),(sx+1,sy+1)
+template <int N> QHD Open make_open(uint64_t hw, uint64_t vw) {
+    BB all = mask_all<N>();
+    BB sh = spread_slots<N>(hw), sv = spread_slots<N>(vw);
+    BB blockD = sh | bb_shl<1>(sh);
+    BB blockU = bb_shl<N>(blockD);
+    BB blockR = sv | bb_shl<N>(sv);
+    BB blockL = bb_shl<1>(blockR);
+    Open o;
+    o.D = all & ~mask_row<N>(N - 1) & ~blockD;
+    o.U = all & ~mask_row<N>(0) & ~blockU;
+    o.R = all & ~mask_col<N>(N - 1) & ~blockR;
+    o.L = all & ~mask_col<N>(0) & ~blockL;
+    return o;
+}
+
+// add one candidate wall to the open masks (orientation 1 = H, 2 = V; slot index i)
+template <int N> QHD Open add_wall(Open o, int orient, int slot) {
+    constexpr int S = N - 1;
+    int t = slot + slot / S;  // top-left tile of the 2x2 block: (slot/S)*N + slot%S
+    if (orient == 1) {
+        o.D = o.D & ~(bb_bit(t) | bb_bit(t + 1));
+        o.U = o.U & ~(bb_bit(t + N) | bb_bit(t + N + 1));
+    } else {
+        o.R = o.R & ~(bb_bit(t) | bb_bit(t + N));
+        o.L = o.L & ~(bb_bit(t + 1) | bb_bit(t + N + 1));
+    }
+    return o;
+}
+
+// Jump rule of game_logic.py:174-188 as "extra edges": for the direction d in which a pawn would step
+// ONTO the obstacle, the set of tiles it lands on instead.
+struct Jumps {
+    int p[4];   // tile from which direction d (0=U,1=D,2=L,3=R) leads onto the obstacle, or -1
+    BB J[4];    // landing tiles for that direction
+};
+
+template <int N> QHD Jumps make_jumps(const Open& o, int e) {
+    Jumps j;
+    const int ex = e / N, ey = e % N;
+    // d = U: mover below the obstacle (p = e + N) moving up
+    j.p[0] = (ex + 1 < N && bb_test(o.U, e + N)) ? e + N : -1;
+    j.J[0] = bb_test(o.U, e) ? bb_bit(e - N)
+                             : ((bb_test(o.L, e) ? bb_bit(e - 1) : bb(0, 0)) | (bb_test(o.R, e) ? bb_bit(e + 1) : bb(0, 0)));
+    // d = D: mover above (p = e - N) moving down
+    j.p[1] = (ex - 1 >= 0 && bb_test(o.D, e - N)) ? e - N : -1;
+    j.J[1] = bb_test(o.D, e) ? bb_bit(e + N)
+                             : ((bb_test(o.L, e) ? bb_bit(e - 1) : bb(0, 0)) | (bb_test(o.R, e) ? bb_bit(e + 1) : bb(0, 0)));
+    // d = L: mover to the right (p = e + 1) moving left
+    j.p[2] = (ey + 1 < N && bb_test(o.L, e + 1)) ? e + 1 : -1;
+    j.J[2] = bb_test(o.L, e) ? bb_bit(e - 1)
+                             : ((bb_test(o.U, e) ? bb_bit(e - N) : bb(0, 0)) | (bb_test(o.D, e) ? bb_bit(e + N) : bb(0, 0)));
+    // d = R: mover to the left (p = e - 1) moving right
+    j.p[3] = (ey - 1 >= 0 && bb_test(o.R, e - 1)) ? e - 1 : -1;
+    j.J[3] = bb_test(o.R, e) ? bb_bit(e + 1)
+                             : ((bb_test(o.U, e) ? bb_bit(e - N) : bb(0, 0)) | (bb_test(o.D, e) ? bb_bit(e + N) : bb(0, 0)));
+    return j;
+}
+
+// game_logic.py:309-324 (bfs) as a flood fill: can a pawn starting on `start` reach any tile of `goal`
+// when the other pawn stands on `obst`?
+template <int N> QHD bool can_reach(const Open& o, int start, int obst, BB goal) {
+    const Jumps j = make_jumps<N>(o, obst);
+    const BB notobst = ~bb_bit(obst);
+    BB reach = bb_bit(start);
+    for (int it = 0; it < N * N; ++it) {
+        if (bb_any(reach & goal)) return true;
+        BB nr = reach | bb_shl<N>(reach & o.D) | bb_shr<N>(reach & o.U) | bb_shl<1>(reach & o.R) | bb_shr<1>(reach & o.L);
+        nr = nr & notobst;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (j.p[d] >= 0 && bb_test(reach, j.p[d])) nr = nr | j.J[d];
+        if (bb_eq(nr, reach)) return false;
+        reach = nr;
+    }
+    return bb_any(reach & goal);
+}
+
+// game_logic.py:120-192 legal_actions_pos(pos) with the enemy pawn on tile `e` (mover's frame).
+// Ordered: U, D, L, R; a jump contributes the straight landing, else (left,right) / (up,down).
+template <int N> QHD int legal_pos_list(const Open& o, int pos, int e, uint8_t* out) {
+    int c = 0;
+    const int dstep[4] = {-N, N, -1, 1};
+    const BB* od[4] = {&o.U, &o.D, &o.L, &o.R};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (!bb_test(*od[d], pos)) continue;
+        int n = pos + dstep[d];
+        if (n != e) { out[c++] = (uint8_t)n; continue; }
+        if (bb_test(*od[d], n)) { out[c++] = (uint8_t)(n + dstep[d]); continue; }
+        if (d < 2) {
+            if (bb_test(o.L, n)) out[c++] = (uint8_t)(n - 1);
+            if (bb_test(o.R, n)) out[c++] = (uint8_t)(n + 1);
+        } else {
+            if (bb_test(o.U, n)) out[c++] = (uint8_t)(n - N);
+            if (bb_test(o.D, n)) out[c++] = (uint8_t)(n + N);
+        }
+    }
+    return c;
+}
+
+// game_logic.py:199-223 can_place_wall, for all slots at once -> bit i set = placement geometrically allowed
+template <int N> QHD void placeable_masks(uint64_t hw, uint64_t vw, uint64_t& hplace, uint64_t& vplace) {
+    constexpr int S = N - 1;
+    constexpr int NW = S * S;
+    const uint64_t ALL = NW == 64 ? ~0ull : ((1ull << (NW % 64)) - 1);
+    uint64_t col0 = 0, colL = 0;
+    for (int sx = 0; sx < S; ++sx) { col0 |= 1ull << (sx * S); colL |= 1ull << (sx * S + S - 1); }
+    uint64_t occ = hw | vw;
+    uint64_t hleft = (hw << 1) & ~col0;    // slot i has an H wall at i-1 in the same row
+    uint64_t hright = (hw >> 1) & ~colL;   // ... at i+1
+    hplace = ALL & ~occ & ~hleft & ~hright;
+    uint64_t vup = vw << S, vdown = vw >> S;
+    vplace = ALL & ~occ & ~vup & ~vdown;
+}
+
+// game_logic.py:227-307 is_goal_possibly_blocked(orientation, pos): >= 2 of {end A, middle, end B} touched
+template <int N> QHD bool possibly_blocking(uint64_t hw, uint64_t vw, int orient, int pos) {
+    constexpr int S = N - 1;
+    const int x = pos / S, y = pos % S;
+    auto H = [&](int i) -> bool { return (hw >> i) & 1; };
+    auto Vv = [&](int i) -> bool { return (vw >> i) & 1; };
+    int cnt;
+    if (orient == 1) {
+        bool left = (y == 0) ||
+                    (y > 0 && (Vv(pos - 1) || (x > 0 && Vv(pos - S - 1)) || (x < S - 1 && Vv(pos + S - 1)))) ||
+                    (y > 1 && H(pos - 2));
+        bool mid = (x > 0 && Vv(pos - S)) || (x < S - 1 && Vv(pos + S));
+        bool right = (y == S - 1) ||
+                     (y < S - 1 && (Vv(pos + 1) || (x > 0 && Vv(pos - S + 1)) || (x < S - 1 && Vv(pos + S + 1)))) ||
+                     (y < S - 2 && H(pos + 2));
+        cnt = (int)left + (int)mid + (int)right;
+    } else {
+        bool top = (x == 0) ||
+                   (x > 0 && (H(pos - S) || (y > 0 && H(pos - S - 1)) || (y < S - 1 && H(pos - S + 1)))) ||
+                   (x > 1 && Vv(pos - 2 * S));
+        bool mid = (y > 0 && H(pos - 1)) || (y < S - 1 && H(pos + 1));
+        bool bot = (x == S - 1) ||
+                   (x < S - 1 && (H(pos + S) || (y > 0 && H(pos + S - 1)) || (y < S - 1 && H(pos + S + 1)))) ||
+                   (x < S - 2 && Vv(pos + 2 * S));
+        cnt = (int)top + (int)mid + (int)bot;
+    }
+    return cnt >= 2;
+}
+
+// game_logic.py:325-348 can_reach_goal for a geometrically placeable candidate
+template <int N> QHD bool wall_keeps_paths(const QState& s, const Open& base, int orient, int pos) {
+    if (!possibly_blocking<N>(s.hw, s.vw, orient, pos)) return true;   // :327-328 prefilter
+    constexpr int V = N * N;
+    const Open o = add_wall<N>(base, orient, pos);
+    const int me = s.ppos, other = V - 1 - s.epos;                     // :136 enemy in mover's frame
+    bool rp = can_reach<N>(o, me, other, mask_row<N>(0));              // :335
+    bool re = can_reach<N>(o, other, me, mask_row<N>(N - 1));          // :344-345, un-rotated
+    return rp && re;
+}
+
+// game_logic.py:366-391 next(action): apply, rotate walls by 180 degrees (= bit reversal of the slot masks), swap
+template <int N> QHD QState next_state(const QState& s, int action) {
+    constexpr int V = N * N, NW = (N - 1) * (N - 1);
+    QState t = s;
+    if (action < V) t.ppos = (uint8_t)action;
+    else if (action < V + NW) { t.hw |= 1ull << (action - V); t.pwl -= 1; }
+    else { t.vw |= 1ull << (action - V - NW); t.pwl -= 1; }
+    QState r;
+    r.hw = brev64(t.hw) >> (64 - NW);
+    r.vw = brev64(t.vw) >> (64 - NW);
+    r.ppos = t.epos; r.pwl = t.ewl;
+    r.epos = t.ppos; r.ewl = t.pwl;
+    r.plies = (uint16_t)(s.plies + 1);
+    r.pad = 0;
+    return r;
+}
+
+template <int N> QHD bool is_lose(const QState& s) { return s.epos / N == 0; }          // :43-46
+QHD bool is_draw(const QState& s, int plies_for_draw) { return s.plies >= plies_for_draw; }  // :49-50
+
+// Serial (one thread per state) legal_actions() -- used by the MCTS kernels for small jobs and by the
+// host self-check.  Returns the count; `out` receives the reference-ordered action ids (:111-115, :352-355).
+template <int N> QHD int legal_actions_serial(const QState& s, uint8_t* out) {
+    constexpr int V = N * N, NW = (N - 1) * (N - 1);
+    const Open base = make_open<N>(s.hw, s.vw);
+    int c = legal_pos_list<N>(base, s.ppos, V - 1 - s.epos, out);
+    if (s.pwl > 0) {
+        uint64_t hp, vp;
+        placeable_masks<N>(s.hw, s.vw, hp, vp);
+        for (int pos = 0; pos < NW; ++pos) {
+            if (((hp >> pos) & 1) && wall_keeps_paths<N>(s, base, 1, pos)) out[c++] = (uint8_t)(V + pos);
+            if (((vp >> pos) & 1) && wall_keeps_paths<N>(s, base, 2, pos)) out[c++] = (uint8_t)(V + NW + pos);
+        }
+    }
+    return c;
+}
+
+}  // namespace aqg

@@ -1,0 +1,127 @@
+"""CPU tests: pin the oracle (oracle/) and the host build of the kernels' rule header against golden
+vectors generated from the REAL reference (tools/gen_golden.py, numpy 2.2.6).  Bit-exact bar."""
+import numpy as np
+import pytest
+
+from oracle import quoridor as oq
+from oracle import mcts as om
+from tests import _util as U
+
+DRAW = {9: 116, 5: 28}
+
+
+def test_reference_known_answers_9x9():
+    k = U.golden("kat_9x9.npz")
+    # the reference's own scenario (test_legal_walls.py:3-21): both orientations illegal at slot 26
+    assert list(k["tlw_wall26"]) == [] and list(k["tlw_pos40"]) == [49, 39] and len(k["tlw_legal"]) == 99
+    rec = k["tlw_state"]
+    assert oq.legal_actions_wall(rec, 26) == []
+    assert oq.legal_actions_pos(rec, 40) == [49, 39]
+    assert oq.legal_actions(rec) == [int(x) for x in k["tlw_legal"]]
+    acts, cnt = U.hc_legal(9, rec)
+    assert list(acts[0, :cnt[0]]) == list(k["tlw_legal"])
+    # initial position: 131 actions, documented prefix
+    init = [int(x) for x in k["init_legal"]]
+    assert len(init) == 131 and init[:7] == [67, 75, 77, 81, 145, 82, 146]
+    assert oq.legal_actions(k["init_state"]) == init
+    assert np.array_equal(oq.init_record(9), k["init_state"])
+    # pawn-jump known answers
+    for rec, exp in zip(k["jump_states"], k["jump_moves"]):
+        exp = [int(x) for x in exp if x >= 0]
+        assert oq.legal_actions_pos(rec, int(rec[0])) == exp
+        a, c = U.hc_legal(9, rec)
+        assert [int(x) for x in a[0, :len(exp)]] == exp
+    # transitions
+    assert np.array_equal(oq.next_batch(np.repeat(k["init_state"][None], 3, 0), k["next_actions"]), k["next_states"])
+    assert np.array_equal(U.hc_next(9, np.repeat(k["init_state"][None], 3, 0), k["next_actions"]), k["next_states"])
+
+
+def test_survey_documented_jumps():
+    # SURVEY 8c item 3 (player[0], enemy[0] own-frame, walls) -> legal_actions_pos
+    cases = [(40, 49, {}, [22, 49, 39, 41]), (40, 49, {20: 1}, [30, 32, 49, 39, 41]),
+             (13, 76, {}, [3, 5, 22, 12, 14]), (40, 41, {}, [31, 49, 38, 41])]
+    for pp, ep, walls, exp in cases:
+        rec = oq.init_record(9)
+        rec[0], rec[2] = pp, ep
+        for s, o in walls.items():
+            rec[4 + s] = o
+        assert oq.legal_actions_pos(rec, pp) == exp
+
+
+@pytest.mark.parametrize("N", [9, 5])
+def test_walk_states_bit_exact(N):
+    g = U.golden(f"walk_{N}x{N}.npz")
+    recs, legal, counts = g["states"], g["legal"], g["counts"]
+    # oracle (C restatement of the reference algorithm)
+    acts, cnt, mask = oq.legal_actions_batch(recs)
+    assert np.array_equal(cnt, counts)
+    assert np.array_equal(acts[:, :U.MAX_LEGAL], legal)
+    assert mask.sum() == counts.sum()
+    # host build of the kernels' bitboard rules
+    hacts, hcnt = U.hc_legal(N, recs)
+    assert np.array_equal(hcnt, counts)
+    assert np.array_equal(hacts, legal)
+    # next() and terminal flags
+    ok = g["actions"] >= 0
+    assert np.array_equal(oq.next_batch(recs[ok], g["actions"][ok]), g["next_states"][ok])
+    assert np.array_equal(U.hc_next(N, recs[ok], g["actions"][ok]), g["next_states"][ok])
+    assert np.array_equal(oq.status_batch(recs, DRAW[N]), g["status"])
+    assert np.array_equal(U.hc_status(N, recs, DRAW[N]), g["status"])
+
+
+def test_pawn_obstacle_counter_examples():
+    # reference says ILLEGAL where a pawn-free flood fill says legal
+    g = U.golden("obstacle_9x9.npz")
+    for rec, legal, absent in zip(g["states"], g["legal"], g["absent"]):
+        exp = [int(x) for x in legal if x >= 0]
+        assert int(absent) not in exp
+        assert oq.legal_actions(rec) == exp
+        a, c = U.hc_legal(9, rec)
+        assert [int(x) for x in a[0, :c[0]]] == exp
+
+
+@pytest.mark.parametrize("N", [9, 5])
+def test_mcts_traces_match_reference(N):
+    g = U.golden(f"mcts_{N}x{N}.npz")
+    n = int(g["count"][0])
+    checked = 0
+    for k in range(n):
+        sims, bias, T = g[f"t{k}_cfg"]
+        if sims > 50 and k % 3:      # keep the CPU suite short; 200-sim traces sampled
+            continue
+        st = oq.State(g[f"t{k}_state"])
+        pol = om.pv_mcts_policy(om.FakeModel(int(bias)), st, float(T), int(sims))
+        assert np.array_equal(np.asarray(pol, dtype=np.float64), g[f"t{k}_policy"]), f"trace {k}"
+        checked += 1
+    assert checked >= 10
+
+
+@pytest.mark.parametrize("N", [9, 5])
+def test_full_games_match_reference(N):
+    g = U.golden(f"games_{N}x{N}.npz")
+    for i in range(int(g["count"][0])):
+        seed, sims, bias = (int(x) for x in g[f"g{i}_cfg"])
+        if N == 9 and i == 1:
+            continue  # 116-ply draw game: covered on the GPU engine test; too slow for the CPU suite
+        rng = np.random.RandomState(seed)   # == np.random.seed(seed) + global np.random.choice in the reference
+        hist = om.play(om.FakeModel(bias), sims, 1.0, N=N, rng=rng)
+        st = g[f"g{i}_states"]
+        assert len(hist) == st.shape[0]
+        for j, (sa, pol, z) in enumerate(hist):
+            assert sa[0] == list(st[j, 0:2]) and sa[1] == list(st[j, 2:4])
+            assert sa[2] == list(st[j, 4:4 + (N - 1) ** 2])
+            assert np.array_equal(np.asarray(pol, dtype=np.float64), g[f"g{i}_policy"][j])
+            assert z == int(g[f"g{i}_z"][j])
+
+
+def test_choice_index_matches_numpy():
+    rng = np.random.RandomState(5)
+    for _ in range(200):
+        n = rng.randint(1, 40)
+        p = rng.randint(0, 7, size=n).astype(np.float64)
+        if p.sum() == 0:
+            p[0] = 1
+        p = p / p.sum()
+        r1 = np.random.RandomState(9)
+        r2 = np.random.RandomState(9)
+        assert r1.choice(n, p=p) == om.choice_index(p, r2.random_sample())
