@@ -1,0 +1,106 @@
+"""ctypes binding of libaqgnn_hip.so (C ABI in include/aqgnn.h).
+
+The HIP library IS the product path.  There is no CPU fallback: if the shared object is missing or a call
+fails, this module raises -- loudly -- instead of computing anything on the host.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaqgnn_hip.so")
+MAX_LEGAL = 136
+ABI_VERSION = 1
+
+_c = ctypes
+_vp, _i32, _f32 = _c.c_void_p, _c.c_int32, _c.c_float
+
+
+class EngineStruct(_c.Structure):
+    """Mirror of `struct aqg_engine` (include/aqgnn.h)."""
+    _fields_ = (
+        [(n, _i32) for n in ("board_size", "num_walls", "plies_for_draw", "num_games", "sims", "node_cap",
+                             "max_plies", "prior_mode", "fake_bias")]
+        + [("c_puct", _f32), ("temperature", _f32)]
+        + [(n, _vp) for n in ("node_p", "node_w", "node_n", "node_action", "node_kids",
+                              "node_count", "root_state", "path", "path_len",
+                              "leaf_flag", "leaf_state",
+                              "game_active", "game_plies", "game_result",
+                              "legal_order", "legal_count", "pooled", "policy", "value",
+                              "hist_state72", "hist_visits", "hist_action",
+                              "counters", "packed_weights")]
+    )
+
+
+SIGNATURES = {
+    "aqg_abi_version": (_c.c_int, []),
+    "aqg_last_error": (_c.c_char_p, []),
+    "aqg_set_option": (_c.c_int, [_c.c_char_p, _c.c_int]),
+    "aqg_legal_actions": (_c.c_int, [_c.c_int, _vp, _c.c_int, _vp, _vp, _vp, _vp]),
+    "aqg_state_next": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_int, _vp, _vp]),
+    "aqg_state_status": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp]),
+    "aqg_gcn_packed_floats": (_c.c_size_t, [_c.c_int]),
+    "aqg_gcn_pack_weights_host": (_c.c_int, [_c.c_int, _c.POINTER(_vp), _vp]),
+    "aqg_gcn_forward_boards": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "aqg_gcn_forward_graph": (_c.c_int, [_c.c_int, _c.c_int, _vp, _c.c_int, _vp, _vp, _vp, _vp, _c.c_int, _vp, _vp,
+                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "aqg_engine_reset": (_c.c_int, [_c.POINTER(EngineStruct), _vp]),
+    "aqg_engine_move": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp]),
+    "aqg_engine_search": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp]),
+    "aqg_engine_root_visits": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libaqgnn_hip.so; raises HipLibraryError if it is missing (build with __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or alphaquoridorgnn_amd/csrc/build.sh")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.aqg_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f"ABI mismatch: library {lib.aqg_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().aqg_last_error().decode(errors="replace")
+        raise HipLibraryError(f"{what} failed: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "HIP entry points take contiguous device tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(device=None):
+    if not torch.cuda.is_available():
+        raise HipLibraryError("no MI355X visible (torch.cuda.is_available() is False): the hot path runs on the GPU only")
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+
+def set_option(name, value):
+    check(load().aqg_set_option(name.encode(), int(value)), f"aqg_set_option({name})")

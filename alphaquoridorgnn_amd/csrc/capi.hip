@@ -1,0 +1,99 @@
+// capi.hip -- extern "C" entry points of libaqgnn_hip.so (declared in include/aqgnn.h).
+#include "aqg_common.hpp"
+#include "../../include/aqgnn.h"
+
+namespace aqg {
+thread_local char g_err[512] = "";
+extern int g_trunk_variant;
+
+size_t packed_floats();
+int pack_weights_host(int N, const float* const* t, float* out);
+int launch_legal_actions(int N, const void* states, int fmt, int B, uint8_t* mask, uint8_t* order, int32_t* count,
+                         const uint8_t* active, hipStream_t st);
+int launch_state_next(int N, const uint8_t* in, const int32_t* actions, int B, uint8_t* out, hipStream_t st);
+int launch_state_status(int N, const uint8_t* in, int B, int draw, uint8_t* flags, hipStream_t st);
+int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
+                              float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
+                              hipStream_t st);
+int launch_gcn_forward_graph(int F, int A, const float* x, int num_nodes, const int32_t* csr_ptr, const int32_t* csr_src,
+                             const float* csr_w, const int32_t* graph_ptr, int num_graphs, const float* packed,
+                             float* work0, float* work1, float* pooled, float* logits, float* policy, float* value_pre,
+                             float* value, hipStream_t st);
+int engine_reset(const aqg_engine& e, hipStream_t st);
+int engine_move(const aqg_engine& e, const double* uniforms, hipStream_t st);
+int engine_search(const aqg_engine& e, const uint8_t* roots72, hipStream_t st);
+int engine_root_visits(const aqg_engine& e, int32_t* visits, uint8_t* actions, int32_t* count, hipStream_t st);
+}  // namespace aqg
+
+using namespace aqg;
+
+extern "C" {
+
+int aqg_abi_version(void) { return AQG_ABI_VERSION; }
+const char* aqg_last_error(void) { return g_err; }
+
+int aqg_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "trunk_variant")) { g_trunk_variant = value ? 1 : 0; return 0; }
+    return fail("unknown option", name ? name : "(null)");
+}
+
+int aqg_legal_actions(int board_size, const uint8_t* states72, int B, uint8_t* mask, uint8_t* order, int32_t* count,
+                      void* stream) {
+    if (B < 0 || (B > 0 && !states72)) return fail("aqg_legal_actions: bad arguments");
+    return launch_legal_actions(board_size, states72, 0, B, mask, order, count, nullptr, (hipStream_t)stream);
+}
+
+int aqg_state_next(int board_size, const uint8_t* states72, const int32_t* actions, int B, uint8_t* out72, void* stream) {
+    if (B < 0 || (B > 0 && (!states72 || !actions || !out72))) return fail("aqg_state_next: bad arguments");
+    return launch_state_next(board_size, states72, actions, B, out72, (hipStream_t)stream);
+}
+
+int aqg_state_status(int board_size, const uint8_t* states72, int B, int plies_for_draw, uint8_t* flags, void* stream) {
+    if (B < 0 || (B > 0 && (!states72 || !flags))) return fail("aqg_state_status: bad arguments");
+    return launch_state_status(board_size, states72, B, plies_for_draw, flags, (hipStream_t)stream);
+}
+
+size_t aqg_gcn_packed_floats(int board_size) { (void)board_size; return packed_floats(); }
+
+int aqg_gcn_pack_weights_host(int board_size, const float* const* tensors_host, float* packed_host) {
+    if (!tensors_host || !packed_host) return fail("aqg_gcn_pack_weights_host: null argument");
+    for (int i = 0; i < 14; ++i) if (!tensors_host[i]) return fail("aqg_gcn_pack_weights_host: null tensor");
+    return pack_weights_host(board_size, tensors_host, packed_host);
+}
+
+int aqg_gcn_forward_boards(int board_size, const void* states, int state_fmt, int B, const float* packed, float* pooled,
+                           float* logits, float* policy, float* value_pre, float* value, void* stream) {
+    if (B < 0 || (B > 0 && (!states || !packed))) return fail("aqg_gcn_forward_boards: bad arguments");
+    if (state_fmt != 0 && state_fmt != 1) return fail("aqg_gcn_forward_boards: state_fmt must be 0 or 1");
+    return launch_gcn_forward_boards(board_size, states, state_fmt, B, packed, pooled, logits, policy, value_pre, value, nullptr,
+                                     (hipStream_t)stream);
+}
+
+int aqg_gcn_forward_graph(int num_features, int num_actions, const float* x, int num_nodes, const int32_t* csr_ptr,
+                          const int32_t* csr_src, const float* csr_w, const int32_t* graph_ptr, int num_graphs,
+                          const float* packed, float* work0, float* work1, float* pooled, float* logits, float* policy,
+                          float* value_pre, float* value, void* stream) {
+    if (!x || !csr_ptr || !csr_src || !csr_w || !graph_ptr || !packed || !work0 || !work1 || !pooled)
+        return fail("aqg_gcn_forward_graph: null argument");
+    return launch_gcn_forward_graph(num_features, num_actions, x, num_nodes, csr_ptr, csr_src, csr_w, graph_ptr, num_graphs,
+                                    packed, work0, work1, pooled, logits, policy, value_pre, value, (hipStream_t)stream);
+}
+
+int aqg_engine_reset(const aqg_engine* e, void* stream) {
+    if (!e) return fail("aqg_engine_reset: null engine");
+    return engine_reset(*e, (hipStream_t)stream);
+}
+int aqg_engine_move(const aqg_engine* e, const double* uniforms, void* stream) {
+    if (!e || !uniforms) return fail("aqg_engine_move: null argument");
+    return engine_move(*e, uniforms, (hipStream_t)stream);
+}
+int aqg_engine_search(const aqg_engine* e, const uint8_t* root_states72, void* stream) {
+    if (!e || !root_states72) return fail("aqg_engine_search: null argument");
+    return engine_search(*e, root_states72, (hipStream_t)stream);
+}
+int aqg_engine_root_visits(const aqg_engine* e, int32_t* visits, uint8_t* actions, int32_t* count, void* stream) {
+    if (!e || !visits || !actions || !count) return fail("aqg_engine_root_visits: null argument");
+    return engine_root_visits(*e, visits, actions, count, (hipStream_t)stream);
+}
+
+}  // extern "C"

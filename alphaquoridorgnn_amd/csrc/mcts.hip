@@ -1,0 +1,462 @@
+// mcts.hip -- K4: batched lock-step PV-MCTS + self-play move loop for gfx950.
+//
+// Semantics reproduced per game (exactly, given the same evaluator outputs and uniforms):
+//   pv_mcts.py:20-95   Node/evaluate/next_child_node/pv_mcts_policy   (C_PUCT 1.25, first-max argmax,
+//                      float32 PUCT arithmetic under NumPy-2 promotion, float64 w accumulators)
+//   self_play.py:40-68 play(): record (state, visit distribution), sample like np.random.choice, next(), z.
+//
+// Layout: one 64-lane wavefront per game.  A game's tree is a flat SoA pool of reference-"Node"s
+// (p, w, n, action, first-child|count); children of a node are contiguous, in State.legal_actions() order,
+// so the PUCT arg-max is a strided wave reduction and "first maximum wins" is (max score, min index).
+// Child STATES are never stored: the descent re-applies next() from the root's 24-byte packed state, so
+// a node costs 21 bytes instead of the reference's full State copy.
+// One simulation = select kernel -> (legal_actions + GNN on the leaf batch) -> expand/backup kernel;
+// every game has exactly one leaf in flight, so no virtual loss is needed and per-game semantics equal the
+// sequential reference.
+#include "aqg_common.hpp"
+#include "../../include/aqgnn.h"
+
+// PUCT scores must be evaluated exactly as written (no fma contraction, IEEE divide/sqrt).
+#pragma clang fp contract(off)
+
+namespace aqg {
+
+int launch_legal_actions(int N, const void* states, int fmt, int B, uint8_t* mask, uint8_t* order, int32_t* count,
+                         const uint8_t* active, hipStream_t st);
+int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
+                              float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
+                              hipStream_t st);
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+struct GameCtx {
+    int g, lane;
+    size_t nb;  // node base of this game
+};
+
+// ------------------------------------------------------------------------------------------------
+// reset: every slot -> initial position (game_logic.py:25-40), active
+// ------------------------------------------------------------------------------------------------
+__global__ void engine_reset_kernel(aqg_engine e) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) {
+        e.counters[0] = e.num_games;
+        for (int i = 1; i < 8; ++i) e.counters[i] = 0;
+    }
+    if (g >= e.num_games) return;
+    const int N = e.board_size;
+    QState s;
+    s.hw = 0; s.vw = 0;
+    s.ppos = (uint8_t)(N * (N - 1) + N / 2); s.pwl = (uint8_t)e.num_walls;
+    s.epos = s.ppos; s.ewl = s.pwl;
+    s.plies = 0; s.pad = 0;
+    store_state(e.root_state, g, s);
+    e.game_active[g] = 1;
+    e.game_plies[g] = 0;
+    e.game_result[g] = 0;
+    e.node_count[g] = 0;
+    e.leaf_flag[g] = 0;
+}
+
+__global__ void engine_set_roots_kernel(aqg_engine e, const uint8_t* __restrict__ roots72) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.num_games) return;
+    store_state(e.root_state, g, unpack72(roots72 + (size_t)g * STATE72));
+    e.game_active[g] = 1;
+    e.game_plies[g] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// begin move: fresh tree per move (pv_mcts.py:81: no tree reuse)
+// ------------------------------------------------------------------------------------------------
+__global__ void engine_begin_move_kernel(aqg_engine e) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.num_games || !e.game_active[g]) return;
+    const size_t nb = (size_t)g * e.node_cap;
+    e.node_p[nb] = 0.f; e.node_w[nb] = 0.0; e.node_n[nb] = 0; e.node_action[nb] = 0xFF; e.node_kids[nb] = 0;
+    e.node_count[g] = 1;
+    const int ply = e.game_plies[g];
+    if (e.hist_visits && ply < e.max_plies) {      // clear this ply's dense visit row (filled by finish_move)
+        const int A = e.board_size * e.board_size + 2 * (e.board_size - 1) * (e.board_size - 1);
+        uint16_t* hv = e.hist_visits + ((size_t)g * e.max_plies + ply) * A;
+        for (int a = 0; a < A; ++a) hv[a] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// select: descend by PUCT to a terminal node (back up at once) or to an unexpanded leaf (emit its state)
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void engine_select_kernel(aqg_engine e) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= e.num_games) return;
+    if (!e.game_active[g]) { if (lane == 0) e.leaf_flag[g] = 0; return; }
+    if (lane == 0) e.leaf_flag[g] = 0;
+    const size_t nb = (size_t)g * e.node_cap;
+    int* path = e.path + (size_t)g * (e.sims + 2);
+    QState s = load_state(e.root_state, 1, g);
+    int node = 0, depth = 0;
+    if (lane == 0) path[0] = 0;
+    int terminal = 0;
+    double value = 0.0;
+    for (;;) {
+        const bool lose = is_lose<N>(s), draw = is_draw(s, e.plies_for_draw);
+        if (lose || draw) {                                    // pv_mcts.py:35-42
+            value = lose ? -1.0 : 0.0;
+            terminal = 1;
+            break;
+        }
+        const uint32_t kids = e.node_kids[nb + node];
+        const int cnt = (int)(kids >> 24), first = (int)(kids & 0xFFFFFF);
+        if (cnt == 0) break;                                   // pv_mcts.py:45 unexpanded leaf
+        // pv_mcts.py:69-78 next_child_node
+        int nloc[3]; float ploc[3]; double wloc[3];
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = lane + 64 * r;
+            if (i < cnt) {
+                nloc[r] = e.node_n[nb + first + i];
+                ploc[r] = e.node_p[nb + first + i];
+                wloc[r] = e.node_w[nb + first + i];
+                t += nloc[r];
+            } else { nloc[r] = 0; ploc[r] = 0.f; wloc[r] = 0.0; }
+        }
+        t = wave_sum_i(t);
+        const float st = (float)sqrt((double)t);              // f32(math.sqrt(t))
+        float best = -INFINITY; int besti = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = lane + 64 * r;
+            if (i < cnt) {
+                const float u = ((e.c_puct * ploc[r]) * st) / (float)(1 + nloc[r]);
+                const float q = nloc[r] ? (float)(-wloc[r] / (double)nloc[r]) : 0.0f;
+                const float sc = q + u;
+                if (sc > best) { best = sc; besti = i; }       // strict > keeps the lowest index within a lane
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {               // (max score, min index) across the wave
+            const float ob = __shfl_xor(best, off);
+            const int oi = __shfl_xor(besti, off);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if (besti == 0x7fffffff) besti = 0;                    // all-NaN guard (np.argmax would return 0)
+        node = first + besti;
+        s = next_state<N>(s, e.node_action[nb + node]);
+        ++depth;
+        if (lane == 0) path[depth] = node;
+    }
+    if (terminal) {
+        if (lane == 0) {
+            double v = value;
+            for (int d = depth; d >= 0; --d) {                 // w += value; n += 1 along the path, sign flips per ply
+                const size_t idx = nb + path[d];
+                e.node_w[idx] += v;
+                e.node_n[idx] += 1;
+                v = -v;
+            }
+            atomicAdd(&e.counters[4], 1);
+        }
+    } else if (lane == 0) {
+        store_state(e.leaf_state, g, s);
+        e.path_len[g] = depth;
+        e.leaf_flag[g] = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// `fake` evaluator (tests): oracle/mcts.py FakeModel, exact integer hash -> f32 priors (written over the
+// first `count` entries of policy[g]) and value.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fnv1a_state72(const uint8_t* r68, int plies) {
+    uint32_t h = 0x811C9DC5u;
+    for (int i = 0; i < 68; ++i) { h ^= r68[i]; h *= 0x01000193u; }
+    h ^= (uint32_t)(plies & 0xFF); h *= 0x01000193u;
+    h ^= (uint32_t)((plies >> 8) & 0xFF); h *= 0x01000193u;
+    return h;
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void engine_fake_eval_kernel(aqg_engine e) {
+    constexpr int V = N * N, A = Geo<N>::A;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= e.num_games || e.leaf_flag[g] != 1) return;
+    const QState s = load_state(e.leaf_state, 1, g);
+    uint8_t rec[STATE72];
+    pack72(s, N, rec);
+    const uint32_t h = fnv1a_state72(rec, s.plies);
+    const int cnt = e.legal_count[g];
+    const uint8_t* ord = e.legal_order + (size_t)g * MAX_LEGAL;
+    const int prow = s.ppos / N;
+    int rl[3]; int tot = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int i = lane + 64 * r;
+        rl[r] = 0;
+        if (i < cnt) {
+            const int a = ord[i];
+            uint32_t x = ((h ^ ((uint32_t)(a + 1) * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 22;
+            int rr = (int)x + 1;
+            if (a < V && (a / N) < prow) rr *= 1 + e.fake_bias;
+            rl[r] = rr; tot += rr;
+        }
+    }
+    tot = wave_sum_i(tot);
+    float* pol = e.policy + (size_t)g * A;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int i = lane + 64 * r;
+        if (i < cnt) pol[i] = (float)rl[r] / (float)tot;
+    }
+    if (lane == 0) e.value[g] = (float)((int)((h * 0xC2B2AE35u) >> 16) - 32768) / 32768.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// expand + backup (pv_mcts.py:47-57, :60-66)
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void engine_expand_backup_kernel(aqg_engine e) {
+    constexpr int A = Geo<N>::A;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= e.num_games || e.leaf_flag[g] != 1) return;
+    const size_t nb = (size_t)g * e.node_cap;
+    const int* path = e.path + (size_t)g * (e.sims + 2);
+    const int depth = e.path_len[g];
+    const int leaf = path[depth];
+    const int cnt = e.legal_count[g];
+    const uint8_t* ord = e.legal_order + (size_t)g * MAX_LEGAL;
+    const float* pol = e.policy + (size_t)g * A;
+    float pl[3];
+    if (e.prior_mode == 0) {       // P0: gather at legal actions, divide by the sum unless 0 (pv_network_cnn.py:129-132)
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = lane + 64 * r;
+            pl[r] = (i < cnt) ? pol[ord[i]] : 0.f;
+            sum += pl[r];
+        }
+        sum = wave_sum_f(sum);
+        const float den = (sum != 0.f) ? sum : 1.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) pl[r] = pl[r] / den;
+    } else {                       // fake evaluator already wrote legal-ordered normalised priors
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = lane + 64 * r;
+            pl[r] = (i < cnt) ? pol[i] : 0.f;
+        }
+    }
+    const int first = e.node_count[g];
+    if (first + cnt <= e.node_cap && cnt > 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = lane + 64 * r;
+            if (i < cnt) {
+                const size_t idx = nb + first + i;
+                e.node_p[idx] = pl[r]; e.node_w[idx] = 0.0; e.node_n[idx] = 0;
+                e.node_action[idx] = ord[i]; e.node_kids[idx] = 0;
+            }
+        }
+    }
+    if (lane == 0) {
+        if (first + cnt <= e.node_cap && cnt > 0) {
+            e.node_kids[nb + leaf] = (uint32_t)first | ((uint32_t)cnt << 24);
+            e.node_count[g] = first + cnt;
+        }
+        double v = (double)e.value[g];                         // value.item() -> python float
+        for (int d = depth; d >= 0; --d) {
+            const size_t idx = nb + path[d];
+            e.node_w[idx] += v;
+            e.node_n[idx] += 1;
+            v = -v;
+        }
+        atomicAdd(&e.counters[3], 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finish move: visits -> policy (pv_mcts.py:88-95), record, np.random.choice, next(), terminal handling
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void engine_finish_move_kernel(aqg_engine e, const double* __restrict__ uniforms) {
+    constexpr int A = Geo<N>::A;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= e.num_games || !e.game_active[g]) return;
+    const size_t nb = (size_t)g * e.node_cap;
+    const uint32_t kids = e.node_kids[nb];
+    const int cnt = (int)(kids >> 24), first = (int)(kids & 0xFFFFFF);
+    const int ply = e.game_plies[g];
+    QState s = load_state(e.root_state, 1, g);
+
+    // history row: state72 + dense visit counts
+    if (ply < e.max_plies) {
+        uint8_t* hs = e.hist_state72 + ((size_t)g * e.max_plies + ply) * STATE72;
+        if (lane == 0) pack72(s, N, hs);
+        uint16_t* hv = e.hist_visits + ((size_t)g * e.max_plies + ply) * A;
+        for (int i = lane; i < cnt; i += 64) hv[e.node_action[nb + first + i]] = (uint16_t)e.node_n[nb + first + i];
+    }
+    if (lane != 0) return;
+
+    int chosen = -1;
+    if (cnt > 0) {
+        int idx = 0;
+        if (e.temperature == 0.f) {                            // one-hot at the first maximum, then choice(p=one-hot)
+            int bestn = -1;
+            for (int i = 0; i < cnt; ++i) { const int n = e.node_n[nb + first + i]; if (n > bestn) { bestn = n; idx = i; } }
+        } else {
+            // boltzman (pv_mcts.py:106-109): xs = n ** (1/T); p = x / sum(xs).  T == 1 is exact (n ** 1.0 == float(n)).
+            const double invT = 1.0 / (double)e.temperature;
+            double tot = 0.0;
+            for (int i = 0; i < cnt; ++i) {
+                const double x = (double)e.node_n[nb + first + i];
+                tot += (e.temperature == 1.f) ? x : pow(x, invT);
+            }
+            // np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, side='right')
+            double last = 0.0;
+            for (int i = 0; i < cnt; ++i) {
+                const double x = (double)e.node_n[nb + first + i];
+                last += ((e.temperature == 1.f) ? x : pow(x, invT)) / tot;
+            }
+            const double u = uniforms[g];
+            double acc = 0.0;
+            idx = 0;
+            for (int i = 0; i < cnt; ++i) {
+                const double x = (double)e.node_n[nb + first + i];
+                acc += ((e.temperature == 1.f) ? x : pow(x, invT)) / tot;
+                if (acc / last <= u) idx = i + 1;
+            }
+            if (idx >= cnt) idx = cnt - 1;
+        }
+        chosen = e.node_action[nb + first + idx];
+    }
+    if (chosen < 0) {
+        // Dead end: legal_actions() is empty.  The reference would re-predict forever-leaf and np.random.choice([])
+        // raises; we abort the game as a draw and count it.
+        e.game_active[g] = 0; e.game_result[g] = 0;
+        atomicAdd(&e.counters[2], 1); atomicAdd(&e.counters[1], 1); atomicSub(&e.counters[0], 1);
+        return;
+    }
+    if (ply < e.max_plies) e.hist_action[(size_t)g * e.max_plies + ply] = (uint8_t)chosen;
+    const QState t = next_state<N>(s, chosen);
+    store_state(e.root_state, g, t);
+    e.game_plies[g] = ply + 1;
+    const bool lose = is_lose<N>(t), draw = is_draw(t, e.plies_for_draw);
+    if (lose || draw) {
+        // first_player_value (self_play.py:22-27): ended state's mover lost; z of ply 0, alternating afterwards (:63-66)
+        int z = 0;
+        if (lose) z = ((t.plies % 2) == 0) ? -1 : 1;
+        e.game_result[g] = (int8_t)z;
+        e.game_active[g] = 0;
+        atomicAdd(&e.counters[1], 1); atomicSub(&e.counters[0], 1);
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void engine_root_visits_kernel(aqg_engine e, int32_t* __restrict__ visits,
+                                                                 uint8_t* __restrict__ actions, int32_t* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= e.num_games) return;
+    const size_t nb = (size_t)g * e.node_cap;
+    const uint32_t kids = e.node_kids[nb];
+    const int cnt = (int)(kids >> 24), first = (int)(kids & 0xFFFFFF);
+    for (int i = lane; i < MAX_LEGAL; i += 64) {
+        visits[(size_t)g * MAX_LEGAL + i] = (i < cnt) ? e.node_n[nb + first + i] : 0;
+        actions[(size_t)g * MAX_LEGAL + i] = (i < cnt) ? e.node_action[nb + first + i] : 0xFF;
+    }
+    if (lane == 0) count[g] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side enqueue (no sync, no allocation)
+// ------------------------------------------------------------------------------------------------
+static int validate(const aqg_engine& e) {
+    const int N = e.board_size;
+    if (!(N == 3 || N == 5 || N == 7 || N == 9)) return fail("unsupported board_size");
+    if (e.num_games <= 0 || e.sims <= 0) return fail("num_games and sims must be positive");
+    if ((long long)e.node_cap >= (1 << 24)) return fail("node_cap must be < 2^24");
+    if (e.node_cap < 1 + MAX_LEGAL) return fail("node_cap too small");
+    if (e.prior_mode == 0 && N != 9) return fail("the fused GNN evaluator is built for 9x9");
+    return 0;
+}
+
+template <int N>
+static int run_sims(const aqg_engine& e, hipStream_t st) {
+    const dim3 grid((e.num_games + 3) / 4), block(256);
+    hipLaunchKernelGGL(engine_begin_move_kernel, dim3((e.num_games + 255) / 256), dim3(256), 0, st, e);
+    for (int sim = 0; sim < e.sims; ++sim) {
+        hipLaunchKernelGGL(engine_select_kernel<N>, grid, block, 0, st, e);
+        if (int r = launch_legal_actions(N, e.leaf_state, 1, e.num_games, nullptr, e.legal_order, e.legal_count, e.leaf_flag, st))
+            return r;
+        if (e.prior_mode == 0) {
+            if (int r = launch_gcn_forward_boards(N, e.leaf_state, 1, e.num_games, e.packed_weights, e.pooled, nullptr, e.policy,
+                                                  nullptr, e.value, e.leaf_flag, st))
+                return r;
+        } else {
+            hipLaunchKernelGGL(engine_fake_eval_kernel<N>, grid, block, 0, st, e);
+        }
+        hipLaunchKernelGGL(engine_expand_backup_kernel<N>, grid, block, 0, st, e);
+    }
+    return check_launch("engine simulation kernels");
+}
+
+template <int N>
+static int do_move(const aqg_engine& e, const double* uniforms, hipStream_t st) {
+    if (int r = run_sims<N>(e, st)) return r;
+    hipLaunchKernelGGL(engine_finish_move_kernel<N>, dim3((e.num_games + 3) / 4), dim3(256), 0, st, e, uniforms);
+    return check_launch("engine_finish_move_kernel");
+}
+
+int engine_reset(const aqg_engine& e, hipStream_t st) {
+    if (int r = validate(e)) return r;
+    hipLaunchKernelGGL(engine_reset_kernel, dim3((e.num_games + 255) / 256), dim3(256), 0, st, e);
+    return check_launch("engine_reset_kernel");
+}
+
+int engine_move(const aqg_engine& e, const double* uniforms, hipStream_t st) {
+    if (int r = validate(e)) return r;
+    switch (e.board_size) {
+        case 3: return do_move<3>(e, uniforms, st);
+        case 5: return do_move<5>(e, uniforms, st);
+        case 7: return do_move<7>(e, uniforms, st);
+        default: return do_move<9>(e, uniforms, st);
+    }
+}
+
+int engine_search(const aqg_engine& e, const uint8_t* roots72, hipStream_t st) {
+    if (int r = validate(e)) return r;
+    hipLaunchKernelGGL(engine_set_roots_kernel, dim3((e.num_games + 255) / 256), dim3(256), 0, st, e, roots72);
+    switch (e.board_size) {
+        case 3: return run_sims<3>(e, st);
+        case 5: return run_sims<5>(e, st);
+        case 7: return run_sims<7>(e, st);
+        default: return run_sims<9>(e, st);
+    }
+}
+
+int engine_root_visits(const aqg_engine& e, int32_t* visits, uint8_t* actions, int32_t* count, hipStream_t st) {
+    const dim3 grid((e.num_games + 3) / 4), block(256);
+    switch (e.board_size) {
+        case 3: hipLaunchKernelGGL(engine_root_visits_kernel<3>, grid, block, 0, st, e, visits, actions, count); break;
+        case 5: hipLaunchKernelGGL(engine_root_visits_kernel<5>, grid, block, 0, st, e, visits, actions, count); break;
+        case 7: hipLaunchKernelGGL(engine_root_visits_kernel<7>, grid, block, 0, st, e, visits, actions, count); break;
+        default: hipLaunchKernelGGL(engine_root_visits_kernel<9>, grid, block, 0, st, e, visits, actions, count); break;
+    }
+    return check_launch("engine_root_visits_kernel");
+}
+
+}  // namespace aqg

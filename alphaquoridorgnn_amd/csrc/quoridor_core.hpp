@@ -170,6 +170,20 @@ template <int N> QHD Open make_open(uint64_t hw, uint64_t vw) {
     return o;
 }
 
+// The same predicate for ONE tile straight from the slot masks (few live registers; used by the GNN trunk
+// to derive node degrees).  bit0 = U, bit1 = D, bit2 = L, bit3 = R open.  game_logic.py:145-167.
+template <int N> QHD int tile_open_bits(uint64_t hw, uint64_t vw, int t) {
+    constexpr int S = N - 1;
+    const int x = t / N, y = t % N;
+    auto H = [&](int sx, int sy) -> bool { return (hw >> (sx * S + sy)) & 1; };
+    auto Vw = [&](int sx, int sy) -> bool { return (vw >> (sx * S + sy)) & 1; };
+    const bool u = x > 0 && !((y < S && H(x - 1, y)) || (y > 0 && H(x - 1, y - 1)));
+    const bool d = x < N - 1 && !((y < S && H(x, y)) || (y > 0 && H(x, y - 1)));
+    const bool l = y > 0 && !((x < S && Vw(x, y - 1)) || (x > 0 && Vw(x - 1, y - 1)));
+    const bool r = y < N - 1 && !((x < S && Vw(x, y)) || (x > 0 && Vw(x - 1, y)));
+    return (int)u | ((int)d << 1) | ((int)l << 2) | ((int)r << 3);
+}
+
 // add one candidate wall to the open masks (orientation 1 = H, 2 = V; slot index i)
 template <int N> QHD Open add_wall(Open o, int orient, int slot) {
     constexpr int S = N - 1;

@@ -1,0 +1,6 @@
+"""Drop-in shim: put alphaquoridorgnn_amd/dropin/ ahead of the reference directory on sys.path and the
+reference's `import pv_mcts` / `from pv_mcts import ...` resolve to the MI355X-native implementation."""
+from alphaquoridorgnn_amd.pv_mcts import *  # noqa: F401,F403
+from alphaquoridorgnn_amd import pv_mcts as _impl
+
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})

@@ -1,0 +1,197 @@
+"""Batched self-play engine: thousands of concurrent PV-MCTS games per MI355X, lock-step simulations.
+
+Host side of aqg_engine_* (include/aqgnn.h).  All state lives in HBM as torch tensors owned by this object;
+every simulation of every game is enqueued by one C call per move (no per-simulation Python, no host sync
+inside a move).  Per-game semantics equal the reference's sequential `pv_mcts_policy` + `play()`
+(pv_mcts.py:20-95, self_play.py:40-68); see csrc/mcts.hip.
+
+Sharding: games are independent, so rank r of W simply owns its own BatchedSelfPlay with its own
+uniform stream; `gather_history` is the single exchange step per generation (all-gather over RCCL/xGMI).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .constants import BOARD_SIZE, board_params
+
+
+class BatchedSelfPlay:
+    def __init__(self, model=None, num_games=2048, sims=50, board_size=BOARD_SIZE, device=None, temperature=1.0,
+                 c_puct=1.25, evaluator="gnn", fake_bias=0, seed=0, record_history=True):
+        """model: GraphPolicyValueNetwork/GNNNetwork (evaluator='gnn'); evaluator='fake' runs the integer-hash
+        evaluator used by the parity tests (oracle/mcts.py FakeModel)."""
+        self.dev = _lib.require_gpu(device)
+        self.lib = _lib.load()
+        self.N = board_size
+        self.A = board_size ** 2 + 2 * (board_size - 1) ** 2
+        self.num_walls, self.plies_for_draw = board_params(board_size)
+        self.G, self.sims = int(num_games), int(sims)
+        self.node_cap = 1 + self.sims * _lib.MAX_LEGAL
+        self.max_plies = self.plies_for_draw
+        self.model = model
+        self.evaluator = evaluator
+        self.gen = torch.Generator(device=self.dev)
+        self.gen.manual_seed(int(seed))
+        G, cap, dev = self.G, self.node_cap, self.dev
+
+        def z(shape, dtype):
+            return torch.zeros(shape, dtype=dtype, device=dev)
+
+        t = self.t = {}
+        t["node_p"] = z((G * cap,), torch.float32)
+        t["node_w"] = z((G * cap,), torch.float64)
+        t["node_n"] = z((G * cap,), torch.int32)
+        t["node_action"] = z((G * cap,), torch.uint8)
+        t["node_kids"] = z((G * cap,), torch.int32)
+        t["node_count"] = z((G,), torch.int32)
+        t["root_state"] = z((G, 24), torch.uint8)
+        t["path"] = z((G, self.sims + 2), torch.int32)
+        t["path_len"] = z((G,), torch.int32)
+        t["leaf_flag"] = z((G,), torch.uint8)
+        t["leaf_state"] = z((G, 24), torch.uint8)
+        t["game_active"] = z((G,), torch.uint8)
+        t["game_plies"] = z((G,), torch.int32)
+        t["game_result"] = z((G,), torch.int8)
+        t["legal_order"] = z((G, _lib.MAX_LEGAL), torch.uint8)
+        t["legal_count"] = z((G,), torch.int32)
+        t["pooled"] = z((G, 128), torch.float32)
+        t["policy"] = z((G, self.A), torch.float32)   # also holds the fake evaluator's legal-ordered priors (count <= A)
+        t["value"] = z((G,), torch.float32)
+        hp = self.max_plies if record_history else 1
+        t["hist_state72"] = z((G, hp, 72), torch.uint8)
+        t["hist_visits"] = z((G, hp, self.A), torch.int16)
+        t["hist_action"] = z((G, hp), torch.uint8)
+        t["counters"] = z((8,), torch.int32)
+        if evaluator == "gnn":
+            if model is None:
+                raise ValueError("evaluator='gnn' needs a model")
+            t["packed_weights"] = model.packed_weights(dev)
+        else:
+            t["packed_weights"] = z((4,), torch.float32)
+
+        e = self.e = _lib.EngineStruct()
+        e.board_size, e.num_walls, e.plies_for_draw = self.N, self.num_walls, self.plies_for_draw
+        e.num_games, e.sims, e.node_cap = G, self.sims, cap
+        e.max_plies = hp if record_history else 0
+        e.prior_mode = 0 if evaluator == "gnn" else 1
+        e.fake_bias = int(fake_bias)
+        e.c_puct, e.temperature = float(c_puct), float(temperature)
+        for name in ("node_p", "node_w", "node_n", "node_action", "node_kids", "node_count", "root_state", "path",
+                     "path_len", "leaf_flag", "leaf_state", "game_active", "game_plies", "game_result", "legal_order",
+                     "legal_count", "pooled", "policy", "value", "hist_state72", "hist_visits", "hist_action", "counters",
+                     "packed_weights"):
+            setattr(e, name, t[name].data_ptr())
+        self.record_history = record_history
+        self.moves_done = 0
+        self.reset()
+
+    # ------------------------------------------------------------------
+    def _stream(self):
+        return _lib.stream_ptr(self.dev)
+
+    def reset(self):
+        _lib.check(self.lib.aqg_engine_reset(ctypes.byref(self.e), self._stream()), "aqg_engine_reset")
+        self.moves_done = 0
+
+    def refresh_weights(self):
+        if self.evaluator == "gnn":
+            self.t["packed_weights"] = self.model.packed_weights(self.dev)
+            self.e.packed_weights = self.t["packed_weights"].data_ptr()
+
+    def move(self, uniforms=None):
+        """One move for every active game.  uniforms: float64 [G] in [0,1) (default: device RNG stream)."""
+        if uniforms is None:
+            uniforms = torch.rand((self.G,), dtype=torch.float64, device=self.dev, generator=self.gen)
+        else:
+            uniforms = torch.as_tensor(uniforms, dtype=torch.float64).to(self.dev).contiguous()
+        self._u = uniforms  # keep alive until the stream has consumed it
+        _lib.check(self.lib.aqg_engine_move(ctypes.byref(self.e), _lib.ptr(uniforms), self._stream()), "aqg_engine_move")
+        self.moves_done += 1
+
+    def counters(self):
+        c = self.t["counters"].cpu().numpy()
+        return dict(active=int(c[0]), finished=int(c[1]), dead_ends=int(c[2]), leaf_evals=int(c[3]), terminal_sims=int(c[4]))
+
+    def play_generation(self, uniforms=None, check_every=4):
+        """Play every slot to termination (one self_play generation's worth of games on this rank).
+        uniforms: optional float64 [max_plies, G] (parity tests).  Returns the counters dict."""
+        ply = 0
+        while True:
+            self.move(None if uniforms is None else uniforms[ply])
+            ply += 1
+            if ply >= self.max_plies or ply % check_every == 0:
+                if self.counters()["active"] == 0 or ply >= self.max_plies:
+                    break
+        return self.counters()
+
+    # ------------------------------------------------------------------ search only (pv_mcts_policy)
+    def search(self, root_states72):
+        roots = torch.as_tensor(root_states72, dtype=torch.uint8).to(self.dev).contiguous().view(self.G, 72)
+        self._roots = roots
+        _lib.check(self.lib.aqg_engine_search(ctypes.byref(self.e), _lib.ptr(roots), self._stream()), "aqg_engine_search")
+        visits = torch.empty((self.G, _lib.MAX_LEGAL), dtype=torch.int32, device=self.dev)
+        actions = torch.empty((self.G, _lib.MAX_LEGAL), dtype=torch.uint8, device=self.dev)
+        count = torch.empty((self.G,), dtype=torch.int32, device=self.dev)
+        _lib.check(self.lib.aqg_engine_root_visits(ctypes.byref(self.e), _lib.ptr(visits), _lib.ptr(actions), _lib.ptr(count),
+                                                   self._stream()), "aqg_engine_root_visits")
+        return visits, actions, count
+
+    # ------------------------------------------------------------------ history
+    def history_tensors(self):
+        """(states72 u8 [P,72], visits i16 [P,A], z i8 [P]) for all finished games on this rank, game-major."""
+        plies = self.t["game_plies"].long()
+        hp = self.t["hist_state72"].shape[1]
+        idx = torch.arange(hp, device=self.dev).unsqueeze(0)
+        valid = (idx < plies.unsqueeze(1)) & (self.t["game_active"] == 0).unsqueeze(1)
+        z0 = self.t["game_result"].to(torch.int8).unsqueeze(1)
+        sign = torch.where(idx % 2 == 0, 1, -1).to(torch.int8)      # z alternates down the history (self_play.py:63-66)
+        z = (z0 * sign)[valid]
+        return self.t["hist_state72"][valid], self.t["hist_visits"][valid], z
+
+    def history(self):
+        """Reference-format history: list of [[player, enemy, walls], policy list[A] (python floats), z]
+        (self_play.py:51-54,:63-66).  policy_i = n_i / sum(n) in float64, exactly like boltzman at T=1."""
+        st, vis, z = (x.cpu().numpy() for x in self.history_tensors())
+        nw = (self.N - 1) ** 2
+        out = []
+        for s, v, zz in zip(st, vis, z):
+            v = v.astype(np.float64)
+            tot = v.sum()
+            pol = (v / tot).tolist() if tot > 0 else [0.0] * self.A
+            out.append([[[int(s[0]), int(s[1])], [int(s[2]), int(s[3])], [int(x) for x in s[4:4 + nw]]], pol, int(zz)])
+        return out
+
+
+def gather_history(states72, visits, z, group=None):
+    """The one exchange step per generation: all-gather the ragged (s, pi, z) tuples of every rank.
+    Counts are gathered first, payloads are padded to the max count (RCCL needs equal sizes) and trimmed after.
+    Works on any torch.distributed backend (nccl == RCCL on ROCm; gloo in the CPU tests)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return states72, visits, z
+    W = dist.get_world_size(group)
+    dev = states72.device
+    n = torch.tensor([states72.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(W)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    m = max(counts)
+    A = visits.shape[1]
+    row = 72 + 2 * A + 1
+    buf = torch.zeros((m, row), dtype=torch.uint8, device=dev)
+    k = states72.shape[0]
+    if k:
+        buf[:k, :72] = states72
+        buf[:k, 72:72 + 2 * A] = visits.contiguous().view(torch.uint8).view(k, 2 * A)
+        buf[:k, 72 + 2 * A] = z.view(torch.uint8)
+    out = torch.empty((W * m, row), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    out = out.view(W, m, row)
+    parts = [out[r, :counts[r]] for r in range(W)]
+    allrows = torch.cat(parts, 0)
+    s = allrows[:, :72].contiguous()
+    v = allrows[:, 72:72 + 2 * A].contiguous().view(torch.int16).view(-1, A)
+    zz = allrows[:, 72 + 2 * A].contiguous().view(torch.int8)
+    return s, v, zz

@@ -1,0 +1,232 @@
+"""Policy-Value GNN -- drop-in for the reference's pv_network_gnn.py, executed by hand-written gfx950 kernels.
+
+Call surface kept (pv_network_gnn.py:17-80): NUM_FEATURES, HIDDEN_DIM, NUM_GCN_LAYERS, POLICY_OUTPUT_SIZE,
+`GraphPolicyValueNetwork(num_features, hidden_dim, num_gcn_layers, policy_output_size)` with submodules
+`gcn_layers`, `policy_head`, `value_head`, `forward(x, edge_index, batch) -> (policy, value)`, `create_network()`.
+state_dict keys follow PyG's GCNConv (`gcn_layers.i.lin.weight [out,in]`, `gcn_layers.i.bias [out]`).
+
+Added (absent from the reference): `forward_states(states72)` -- the fused board-graph path the
+self-play engine uses -- and `GNNNetwork`, the BaseNetwork-style wrapper (BaseNetwork.py:9-54) giving
+`predict / prep_for_inference / preprocess_input / name`.
+
+All arithmetic runs in libaqgnn_hip.so (fp32, f32-input MFMA); there is no torch/CPU forward in this file.
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .constants import BOARD_SIZE, PV_NETWORK_PATH
+from . import game_logic
+
+NUM_FEATURES = 6      # pv_network_gnn.py:17
+HIDDEN_DIM = 128      # :18
+NUM_GCN_LAYERS = 3    # :19
+POLICY_OUTPUT_SIZE = BOARD_SIZE ** 2 + 2 * (BOARD_SIZE - 1) ** 2  # :20
+
+STATE_DICT_KEYS = [
+    "gcn_layers.0.lin.weight", "gcn_layers.0.bias", "gcn_layers.1.lin.weight", "gcn_layers.1.bias",
+    "gcn_layers.2.lin.weight", "gcn_layers.2.bias", "policy_head.0.weight", "policy_head.0.bias",
+    "policy_head.2.weight", "policy_head.2.bias", "value_head.0.weight", "value_head.0.bias",
+    "value_head.2.weight", "value_head.2.bias",
+]
+
+
+class GCNConv(nn.Module):
+    """Parameter container with PyG's GCNConv naming and initialisation (lin: Glorot-uniform, no bias; bias: zeros).
+    The layer arithmetic is fused into the network-level HIP kernels, so it has no stand-alone forward."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        a = math.sqrt(6.0 / (in_channels + out_channels))
+        with torch.no_grad():
+            self.lin.weight.uniform_(-a, a)
+
+    def forward(self, x, edge_index):
+        raise NotImplementedError("GCNConv is evaluated inside GraphPolicyValueNetwork.forward (fused HIP kernels)")
+
+
+class GraphPolicyValueNetwork(nn.Module):
+    def __init__(self, num_features=NUM_FEATURES, hidden_dim=HIDDEN_DIM, num_gcn_layers=NUM_GCN_LAYERS,
+                 policy_output_size=POLICY_OUTPUT_SIZE, board_size=BOARD_SIZE):
+        super().__init__()
+        if (num_features, hidden_dim, num_gcn_layers) != (NUM_FEATURES, HIDDEN_DIM, NUM_GCN_LAYERS):
+            raise ValueError("the HIP kernels are built for the reference configuration 6/128/3 (pv_network_gnn.py:17-19)")
+        self.num_features = num_features
+        self.hidden_dim = hidden_dim
+        self.num_gcn_layers = num_gcn_layers
+        self.policy_output_size = policy_output_size
+        self.board_size = board_size
+
+        self.gcn_layers = nn.ModuleList()
+        self.gcn_layers.append(GCNConv(num_features, hidden_dim))
+        for _ in range(num_gcn_layers - 1):
+            self.gcn_layers.append(GCNConv(hidden_dim, hidden_dim))
+        self.policy_head = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2), nn.ReLU(),
+                                         nn.Linear(hidden_dim // 2, policy_output_size), nn.Softmax(dim=1))
+        self.value_head = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2), nn.ReLU(),
+                                        nn.Linear(hidden_dim // 2, 1), nn.Tanh())
+        self._packed = None
+        self._packed_key = None
+
+    # ---------------------------------------------------------------- weight packing
+    def packed_weights(self, device):
+        """float32 device buffer in the kernel layout (include/aqgnn.h); rebuilt when a parameter changes."""
+        sd = self.state_dict()
+        key = (str(device),) + tuple((sd[k].data_ptr(), sd[k]._version) for k in STATE_DICT_KEYS)
+        if self._packed is None or key != self._packed_key:
+            lib = _lib.load()
+            host = [sd[k].detach().to("cpu", torch.float32).contiguous() for k in STATE_DICT_KEYS]
+            arr = (ctypes.c_void_p * 14)(*[ctypes.c_void_p(t.data_ptr()) for t in host])
+            out = torch.empty(lib.aqg_gcn_packed_floats(self.board_size), dtype=torch.float32)
+            _lib.check(lib.aqg_gcn_pack_weights_host(self.board_size, arr, ctypes.c_void_p(out.data_ptr())),
+                       "aqg_gcn_pack_weights_host")
+            self._packed = out.to(device)
+            self._packed_key = key
+        return self._packed
+
+    # ---------------------------------------------------------------- fused board path
+    def forward_states(self, states72, want_logits=False, state_fmt=0):
+        """states72: uint8 [B,72] device tensor (state_fmt=0) -> (policy [B,A] softmaxed, value [B,1] tanh'ed);
+        with want_logits also returns (logits [B,A], value_pre [B])."""
+        dev = _lib.require_gpu(states72.device)
+        lib = _lib.load()
+        B = states72.shape[0]
+        A = self.policy_output_size
+        f32 = dict(dtype=torch.float32, device=dev)
+        pooled = torch.empty((B, HIDDEN_DIM), **f32)
+        policy = torch.empty((B, A), **f32)
+        value = torch.empty((B,), **f32)
+        logits = torch.empty((B, A), **f32) if want_logits else None
+        vpre = torch.empty((B,), **f32) if want_logits else None
+        _lib.check(lib.aqg_gcn_forward_boards(self.board_size, _lib.ptr(states72), state_fmt, B,
+                                              _lib.ptr(self.packed_weights(dev)), _lib.ptr(pooled), _lib.ptr(logits),
+                                              _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value), _lib.stream_ptr(dev)),
+                   "aqg_gcn_forward_boards")
+        if want_logits:
+            return policy, value.unsqueeze(1), logits, vpre
+        return policy, value.unsqueeze(1)
+
+    # ---------------------------------------------------------------- generic (x, edge_index, batch) path
+    @staticmethod
+    def _build_csr(edge_index, num_nodes):
+        """gcn_norm (PyG defaults: weight 1, add remaining self loops, symmetric normalisation) -> CSR by destination."""
+        dev = edge_index.device
+        src, dst = edge_index[0].long(), edge_index[1].long()
+        has_loop = torch.zeros(num_nodes, dtype=torch.bool, device=dev)
+        has_loop[src[src == dst]] = True
+        extra = torch.nonzero(~has_loop).flatten()
+        src = torch.cat([src, extra])
+        dst = torch.cat([dst, extra])
+        deg = torch.zeros(num_nodes, dtype=torch.float32, device=dev).index_add_(0, dst, torch.ones_like(dst, dtype=torch.float32))
+        dis = deg.pow(-0.5)
+        dis[torch.isinf(dis)] = 0
+        w = dis[src] * dis[dst]
+        order = torch.argsort(dst, stable=True)
+        counts = torch.bincount(dst, minlength=num_nodes)
+        ptr = torch.zeros(num_nodes + 1, dtype=torch.int32, device=dev)
+        ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        return ptr, src[order].to(torch.int32).contiguous(), w[order].contiguous()
+
+    def forward(self, x, edge_index, batch):
+        """pv_network_gnn.py:53-64.  x [sum V, 6] float32, edge_index [2,E] int64, batch [sum V] int64 (sorted)."""
+        dev = _lib.require_gpu(x.device)
+        lib = _lib.load()
+        x = x.to(torch.float32).contiguous()
+        n = x.shape[0]
+        if x.shape[1] != NUM_FEATURES:
+            raise ValueError(f"x must have {NUM_FEATURES} features")
+        batch = batch.long()
+        if n > 1 and bool((batch[1:] < batch[:-1]).any()):
+            raise ValueError("batch must be sorted (PyG Batch convention)")
+        G = int(batch.max().item()) + 1 if n else 0
+        gptr = torch.zeros(G + 1, dtype=torch.int32, device=dev)
+        gptr[1:] = torch.cumsum(torch.bincount(batch, minlength=G), 0).to(torch.int32)
+        ptr, csr_src, csr_w = self._build_csr(edge_index.to(dev), n)
+        A = self.policy_output_size
+        f32 = dict(dtype=torch.float32, device=dev)
+        w0, w1 = torch.empty((n, HIDDEN_DIM), **f32), torch.empty((n, HIDDEN_DIM), **f32)
+        pooled = torch.empty((G, HIDDEN_DIM), **f32)
+        policy, value = torch.empty((G, A), **f32), torch.empty((G,), **f32)
+        logits, vpre = torch.empty((G, A), **f32), torch.empty((G,), **f32)
+        _lib.check(lib.aqg_gcn_forward_graph(NUM_FEATURES, A, _lib.ptr(x), n, _lib.ptr(ptr), _lib.ptr(csr_src), _lib.ptr(csr_w),
+                                             _lib.ptr(gptr), G, _lib.ptr(self.packed_weights(dev)), _lib.ptr(w0), _lib.ptr(w1),
+                                             _lib.ptr(pooled), _lib.ptr(logits), _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value),
+                                             _lib.stream_ptr(dev)), "aqg_gcn_forward_graph")
+        self.last_logits, self.last_value_pre = logits, vpre
+        return policy, value.unsqueeze(1)
+
+
+class GNNNetwork(GraphPolicyValueNetwork):
+    """BaseNetwork-style wrapper (BaseNetwork.py:9-54; reference implementation of the contract:
+    pv_network_cnn.py:50-140) around the GNN.  `optimised_model` of the reference (TensorRT) has no counterpart:
+    the HIP kernels are the inference path."""
+
+    def __init__(self):
+        super().__init__(NUM_FEATURES, HIDDEN_DIM, NUM_GCN_LAYERS, POLICY_OUTPUT_SIZE)
+        self._name = "GNN"
+
+    @property
+    def name(self):
+        return self._name
+
+    def prep_for_inference(self, model_path):
+        """BaseNetwork.py:21-32 minus the TensorRT compile."""
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.load_state_dict(torch.load(model_path, map_location=device, weights_only=True))
+        self.eval()
+        self.to(device)
+        if device == "cuda":
+            self.packed_weights(torch.device("cuda", torch.cuda.current_device()))
+
+    def preprocess_input(self, game_state_arrays):
+        """List of State.to_array() triples -> uint8 [n,72] state records (the input the GNN kernels accept).
+        plies_played is not part of to_array() and is not a network input; it is stored as 0."""
+        out = np.zeros((len(game_state_arrays), 72), dtype=np.uint8)
+        for i, (player, enemy, walls) in enumerate(game_state_arrays):
+            out[i] = game_logic.pack_state72(player, enemy, walls, 0, self.board_size)
+        return out
+
+    def predict_batch(self, states72):
+        """Batched predict: device uint8 [B,72] -> (policy [B,A] over ALL actions, value [B])."""
+        policy, value = self.forward_states(states72)
+        return policy, value[:, 0]
+
+    def predict(self, state, device=None):
+        """pv_network_cnn.py:117-137: PMF over state.legal_actions() (in that order) as float32 numpy + python float."""
+        dev = _lib.require_gpu()
+        rec = torch.from_numpy(state.record() if hasattr(state, "record") else
+                               game_logic.pack_state72(state.player, state.enemy, state.walls, state.plies_played, state.N)
+                               ).to(dev).unsqueeze(0)
+        with torch.inference_mode():
+            policy, value = self.forward_states(rec)
+            _, order, count = game_logic.legal_actions_batch(rec, self.board_size, want_mask=False)
+            n = int(count.item())
+            pol = policy[0][order[0, :n].long()]
+            s = torch.sum(pol)
+            pol = pol / (s if s else 1)
+        return pol.cpu().numpy(), value.item()
+
+    def train_model(self, data_loader, optimizer, loss_fn, device='cpu', num_epochs=10):
+        pass  # stub in the reference as well (pv_network_cnn.py:139-140); training is SURVEY 8(f1), a later row
+
+
+def create_network():
+    """pv_network_gnn.py:68-80 (path taken from constants.PV_NETWORK_PATH like pv_network_cnn.py:144-155)."""
+    model_path = PV_NETWORK_PATH + 'best.pth'
+    if os.path.exists(model_path):
+        return
+    model = GraphPolicyValueNetwork(NUM_FEATURES, HIDDEN_DIM, NUM_GCN_LAYERS, POLICY_OUTPUT_SIZE)
+    os.makedirs(PV_NETWORK_PATH, exist_ok=True)
+    torch.save(model.state_dict(), model_path)
+
+
+if __name__ == '__main__':
+    create_network()

@@ -1,0 +1,89 @@
+"""Self-play -- drop-in for the reference's self_play.py, running whole generations on the batched HIP engine.
+
+Call surface kept (self_play.py:19-95): SP_GAME_COUNT, SP_TEMPERATURE, first_player_value, write_data, play,
+self_play.  `self_play()` plays SP_GAME_COUNT games CONCURRENTLY on this rank's GPU (sharded over ranks when
+torch.distributed is initialised: rank r plays its share, then one all-gather of (s, pi, z) over RCCL/xGMI and
+rank 0 writes the single history file, like self_play.py:84,:91).
+"""
+import os
+import pickle
+from datetime import datetime
+
+import numpy as np
+import torch
+
+from . import pv_mcts
+from .constants import PV_NETWORK_PATH, BOARD_SIZE
+from .engine import BatchedSelfPlay, gather_history
+from .pv_network_gnn import GNNNetwork, POLICY_OUTPUT_SIZE
+
+SP_GAME_COUNT = 50    # Number of games for self-play (self_play.py:19; 25000 in the original version)
+SP_TEMPERATURE = 1.0  # Temperature parameter for Boltzmann distribution (self_play.py:20)
+
+
+def first_player_value(ended_state):
+    """1: first player wins, -1: first player loses, 0: draw (self_play.py:22-27)."""
+    if ended_state.is_lose():
+        return -1 if ended_state.is_first_player() else 1
+    return 0
+
+
+def write_data(history):
+    """Save training data to ./data/YYYYMMDDhhmmss.history (self_play.py:30-37)."""
+    now = datetime.now()
+    os.makedirs('./data/', exist_ok=True)
+    path = './data/{:04}{:02}{:02}{:02}{:02}{:02}.history'.format(
+        now.year, now.month, now.day, now.hour, now.minute, now.second)
+    with open(path, mode='wb') as f:
+        pickle.dump(history, f)
+    return path
+
+
+def _history_rows(states72, visits, z, board_size):
+    nw = (board_size - 1) ** 2
+    st, vis, zz = states72.cpu().numpy(), visits.cpu().numpy().astype(np.float64), z.cpu().numpy()
+    out = []
+    for s, v, r in zip(st, vis, zz):
+        tot = v.sum()
+        pol = (v / tot).tolist() if tot > 0 else [0.0] * v.shape[0]
+        out.append([[[int(s[0]), int(s[1])], [int(s[2]), int(s[3])], [int(x) for x in s[4:4 + nw]]], pol, int(r)])
+    return out
+
+
+def play(model, device=None, uniforms=None):
+    """Execute one self-play game (self_play.py:40-68) -- a generation of one game on the engine.
+    Returns [[state_array, policy list[POLICY_OUTPUT_SIZE], z], ...]."""
+    eng = BatchedSelfPlay(model, num_games=1, sims=pv_mcts.PV_EVALUATE_COUNT, board_size=BOARD_SIZE,
+                          temperature=SP_TEMPERATURE, seed=int(np.random.randint(0, 2 ** 31 - 1)))
+    eng.play_generation(uniforms=uniforms, check_every=1)
+    return eng.history()
+
+
+def self_play(model=None, games=None):
+    """Perform self-play games and save the training data (self_play.py:71-95)."""
+    import torch.distributed as dist
+    if model is None:
+        model = GNNNetwork()
+        model.prep_for_inference(model_path=PV_NETWORK_PATH + 'best.pth')
+    total = SP_GAME_COUNT if games is None else games
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    mine = total // world + (1 if rank < total % world else 0)
+    st = torch.zeros((0, 72), dtype=torch.uint8, device='cuda')
+    vis = torch.zeros((0, POLICY_OUTPUT_SIZE), dtype=torch.int16, device='cuda')
+    z = torch.zeros((0,), dtype=torch.int8, device='cuda')
+    if mine > 0:
+        eng = BatchedSelfPlay(model, num_games=mine, sims=pv_mcts.PV_EVALUATE_COUNT, board_size=BOARD_SIZE,
+                              temperature=SP_TEMPERATURE, seed=1234 + rank)
+        c = eng.play_generation()
+        print(f'\rSelf-play (rank {rank}: {c["finished"]}/{mine} games)', end='')
+        st, vis, z = eng.history_tensors()
+    st, vis, z = gather_history(st, vis, z)
+    print('')
+    if rank == 0:
+        write_data(_history_rows(st, vis, z, BOARD_SIZE))
+    del model
+    torch.cuda.empty_cache()
+
+
+if __name__ == '__main__':
+    self_play()

@@ -1,0 +1,146 @@
+/*
+ * include/aqgnn.h -- C ABI of libaqgnn_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (ApproximateCaesar/AlphaQuoridorGNN) is pure Python and has no FFI layer; its boundary is
+ * the Python module surface.  This library is the native layer *beneath* that surface: each
+ * entry point is what a ctypes binding inside the reference's own modules would call for the hot path.  The
+ * reference interface each one replaces is cited as file:line (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the parameter name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is stream-ordered and
+ *     no entry point synchronises, allocates or frees device memory;
+ *   - return value 0 = success, negative = error; aqg_last_error() returns a thread-local message;
+ *   - `board_size` N in {3,5,7,9}; V = N*N tiles, NW = (N-1)^2 wall slots, A = V + 2*NW actions (209 at 9x9).
+ *
+ * state72 record (72 bytes) == State.to_array() (game_logic.py:96-100) flattened, plus plies and N:
+ *   [0] player pos  [1] player walls left  [2] enemy pos (ENEMY's frame)  [3] enemy walls left
+ *   [4..67] walls[64] (0 none / 1 horizontal / 2 vertical; first NW used)  [68..69] plies_played u16 LE
+ *   [70] N  [71] 0
+ */
+#ifndef AQGNN_H
+#define AQGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AQG_MAX_LEGAL 136 /* >= 5 pawn moves + 128 wall placements */
+#define AQG_ABI_VERSION 1
+
+int aqg_abi_version(void);
+const char* aqg_last_error(void);
+/* tuning knobs: "trunk_variant" 0 = weights resident in registers, 1 workgroup/CU; 1 = per-layer re-fetch, 2/CU */
+int aqg_set_option(const char* name, int value);
+
+/* ------------------------------------------------------------------ game rules (game_logic.py) */
+
+/* State.legal_actions()  game_logic.py:103-117 (+ :120-192 pawn moves, :195-357 wall legality incl. the
+ * touch-count prefilter :227-307 and the jump-aware BFS :309-348), batched.
+ *   mask  [B, A]  u8, 1 = legal (may be NULL)
+ *   order [B, AQG_MAX_LEGAL] u8 action ids in the reference's list order (pawn U,D,L,R/jumps, then per slot
+ *         H,V interleaved), entries >= count are 0xFF (may be NULL)
+ *   count [B] i32 number of legal actions (may be NULL) */
+int aqg_legal_actions(int board_size, const uint8_t* states72, int B, uint8_t* mask, uint8_t* order,
+                      int32_t* count, void* stream);
+
+/* State.next(action)  game_logic.py:366-391 (incl. rotate_walls :359-364), batched. */
+int aqg_state_next(int board_size, const uint8_t* states72, const int32_t* actions, int B, uint8_t* out72,
+                   void* stream);
+
+/* is_lose / is_draw  game_logic.py:43-54 : flags[b] = (lose ? 1 : 0) | (draw ? 2 : 0). */
+int aqg_state_status(int board_size, const uint8_t* states72, int B, int plies_for_draw, uint8_t* flags,
+                     void* stream);
+
+/* ------------------------------------------------------------------ GNN (pv_network_gnn.py) */
+
+/* Packed weights: one float32 device buffer holding the state_dict of GraphPolicyValueNetwork
+ * (pv_network_gnn.py:23-51) in kernel order.  Offsets in floats (9x9: F=6, H=128, A=209):
+ *   W1  [H][8]   gcn_layers.0.lin.weight [H,F] rows padded to 8     b1 [H]
+ *   W2T [H][H]   gcn_layers.1.lin.weight transposed ([k][n])        b2 [H]
+ *   W3T [H][H]   gcn_layers.2.lin.weight transposed                 b3 [H]
+ *   HW1T[H][H]   hidden layer of both heads, [k][unit]: unit<H/2 policy_head.0, else value_head.0    hb1 [H]
+ *   PW2T[H/2][256] policy_head.2.weight transposed ([k][a], a padded to 256)   pb2 [256]
+ *   VW2 [H/2]    value_head.2.weight                                vb2 [1] (+3 pad)
+ * aqg_gcn_packed_floats() returns the total; aqg_gcn_pack_weights_host() fills a HOST buffer from the 14
+ * state_dict tensors given as HOST float32 pointers in the key order of KEYS in INTEGRATION.md. */
+size_t aqg_gcn_packed_floats(int board_size);
+int aqg_gcn_pack_weights_host(int board_size, const float* const* tensors_host, float* packed_host);
+
+/* GraphPolicyValueNetwork.forward  pv_network_gnn.py:53-64 on B boards given as state72 records: node
+ * features = pv_network_cnn.py:88-114 read as [V,6]; graph = wall-cut 4-neighbour grid;
+ * 3 x (GCNConv + ReLU) -> global_mean_pool -> heads.  fp32 throughout (f32-input MFMA for the contractions).
+ *   pooled    [B,128]  workspace/out: mean-pooled trunk features
+ *   logits    [B,A]    pre-softmax policy (may be NULL)
+ *   policy    [B,A]    Softmax output == module output (may be NULL)
+ *   value_pre [B]      pre-tanh value (may be NULL)
+ *   value     [B]      Tanh output == module output (may be NULL)
+ * state_fmt: 0 = state72 records, 1 = 24-byte packed QState (engine-internal). */
+int aqg_gcn_forward_boards(int board_size, const void* states, int state_fmt, int B, const float* packed,
+                           float* pooled, float* logits, float* policy, float* value_pre, float* value,
+                           void* stream);
+
+/* Same network on an arbitrary batched graph: forward(x, edge_index, batch)  pv_network_gnn.py:53.
+ *   x [num_nodes, F] f32;  csr_ptr [num_nodes+1] i32 / csr_src [E'] i32 / csr_w [E'] f32 : incoming edges of
+ *   each node INCLUDING self loops with the gcn_norm weights already attached (built by the host wrapper
+ *   from edge_index with torch ops);  graph_ptr [num_graphs+1] i32 node ranges (batch must be sorted);
+ *   work0/work1 [num_nodes,128] f32 scratch. */
+int aqg_gcn_forward_graph(int num_features, int num_actions, const float* x, int num_nodes,
+                          const int32_t* csr_ptr, const int32_t* csr_src, const float* csr_w,
+                          const int32_t* graph_ptr, int num_graphs, const float* packed, float* work0,
+                          float* work1, float* pooled, float* logits, float* policy, float* value_pre,
+                          float* value, void* stream);
+
+/* ------------------------------------------------------------------ batched PV-MCTS self-play (pv_mcts.py, self_play.py) */
+
+/* All engine memory is owned by the caller (the Python host allocates torch tensors); this struct only
+ * carries device pointers + sizes.  G concurrent games, one wavefront per game, lock-step simulations. */
+typedef struct aqg_engine {
+    int32_t board_size, num_walls, plies_for_draw;
+    int32_t num_games;        /* G: concurrent game slots */
+    int32_t sims;             /* PV_EVALUATE_COUNT  pv_mcts.py:18 */
+    int32_t node_cap;         /* nodes per game tree >= 1 + sims * AQG_MAX_LEGAL */
+    int32_t max_plies;        /* history rows per game slot (>= plies_for_draw) */
+    int32_t prior_mode;       /* 0: network policy gathered at legal actions + renormalised (pv_network_cnn.py:129-132)
+                                 1: `fake` integer-hash evaluator (tests; oracle/mcts.py FakeModel) */
+    int32_t fake_bias;
+    float c_puct;             /* 1.25  pv_mcts.py:71 */
+    float temperature;        /* SP_TEMPERATURE self_play.py:20; 1.0 exact, 0 = argmax */
+    /* tree pools, [G * node_cap] */
+    float* node_p; double* node_w; int32_t* node_n; uint8_t* node_action; uint32_t* node_kids;
+    /* per game, [G] */
+    int32_t* node_count; uint8_t* root_state /* [G,24] */; int32_t* path /* [G, sims+2] */; int32_t* path_len;
+    uint8_t* leaf_flag /* [G] 1 = this simulation's leaf needs an evaluation */; uint8_t* leaf_state /* [G,24] */;
+    uint8_t* game_active /* [G] */; int32_t* game_plies /* [G] rows recorded */; int8_t* game_result /* [G] z of ply 0, valid when inactive */;
+    /* evaluation buffers, [G,...] */
+    uint8_t* legal_order /* [G,AQG_MAX_LEGAL] */; int32_t* legal_count; float* pooled /* [G,128] */;
+    float* policy /* [G,A] */; float* value /* [G] */;
+    /* history, per slot: [G, max_plies, ...] */
+    uint8_t* hist_state72; uint16_t* hist_visits /* [G,max_plies,A] root child visit counts, dense by action */;
+    uint8_t* hist_action /* [G,max_plies] */;
+    /* counters [8] i32: 0 active games, 1 finished games, 2 dead-end aborts, 3 leaf evals, 4 terminal sims */
+    int32_t* counters;
+    const float* packed_weights;
+} aqg_engine;
+
+/* Reset all G slots to the initial position (State() game_logic.py:25-40) and mark them active. */
+int aqg_engine_reset(const aqg_engine* e_host, void* stream);
+/* One self-play move for every active game == pv_mcts_policy (pv_mcts.py:20-95, `sims` lock-step simulations:
+ * select :69-78, terminal/leaf evaluate :33-57, backup) + the body of play() (self_play.py:45-60): record
+ * (state, visit counts), sample the action with uniforms[g] exactly like np.random.choice (self_play.py:57),
+ * apply next(); finished games get z (self_play.py:22-27,:63-66) and go inactive.
+ *   uniforms [G] f64 in [0,1). */
+int aqg_engine_move(const aqg_engine* e_host, const double* uniforms, void* stream);
+/* pv_mcts_policy only, for caller-supplied root states (no history, no transition): after the call
+ * node_n of the root's children holds the visit counts; `root_states72` [G,72]. */
+int aqg_engine_search(const aqg_engine* e_host, const uint8_t* root_states72, void* stream);
+/* Read back the root's children after a search: visits [G,AQG_MAX_LEGAL] i32, actions [G,AQG_MAX_LEGAL] u8, count [G]. */
+int aqg_engine_root_visits(const aqg_engine* e_host, int32_t* visits, uint8_t* actions, int32_t* count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AQGNN_H */

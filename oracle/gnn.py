@@ -148,3 +148,21 @@ def init_params(seed=0, N=9, num_features=6, hidden=128, layers=3):
         p[name + ".weight"] = rng.uniform(-a, a, size=(o, i)).astype(np.float32)
         p[name + ".bias"] = rng.uniform(-a, a, size=(o,)).astype(np.float32)
     return p
+
+
+class OracleModel:
+    """predict() contract of pv_network_cnn.py:117-137 on top of the fp64 forward above (used by the tests and by
+    bench.py's cpu_baseline leg together with oracle/mcts.py)."""
+
+    def __init__(self, params):
+        self.params = params
+        self.calls = 0
+
+    def predict(self, state, device=None):
+        self.calls += 1
+        out = forward_states(self.params, state.rec[None])
+        legal = state.legal_actions()
+        pol = out["policy"][0][legal].astype(np.float32)
+        s = pol.sum()
+        pol = pol / (s if s else 1)
+        return pol.astype(np.float32), float(np.float32(out["value"][0]))
