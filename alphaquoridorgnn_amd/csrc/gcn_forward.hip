@@ -105,138 +105,30 @@ __device__ __forceinline__ float dinv_of(int deg) {
 
 __device__ __forceinline__ float dinv_of_bits(int bits) { return dinv_of(1 + __popc(bits)); }
 
-struct TrunkSmem {
-    float H[81 * LD];          // in-place activation image
-    float X0[81 * FPAD];       // node features
-    float coef[5][96];         // self, U, D, L, R gather coefficients per node (0 when the edge is cut)
-    float part[8][HID];        // pooling partials
+// Diagnostic build only (-DAQG_STAMP, never shipped): per-phase s_memtime sums of workgroup 0 / wave 0 are
+// written behind the pooled rows (pooled + B*128, as 16 x u64).  In the real kernel no stamp executes.
+#ifdef AQG_STAMP
+#define AQG_STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int st_n = 0;
+#define AQG_STAMP_AT(i) { unsigned long long st_now = __builtin_readcyclecounter(); st_sum[i] += st_now - st_prev; st_prev = st_now; }
+#else
+#define AQG_STAMP_DECL
+#define AQG_STAMP_AT(i)
+#endif
+
+struct alignas(16) TrunkSmem {
+    alignas(16) float H[81 * LD];      // in-place activation image, [node][channel]
+    alignas(16) float X0[81 * FPAD];   // node features
+    alignas(16) float AX[81 * FPAD];   // A_hat * X0 (layer-1 input after the 6-wide gather)
+    alignas(16) float coef[96][8];     // per node: self, U, D, L, R gather coefficients (0 when the edge is cut), 3 pad
+    int obits[96];                     // per node: open-edge bits (U,D,L,R) -- setup step 1 -> step 2
 };
 
-// ---- one dense layer: acc = H[0..79] x W (MFMA), row 80 on VALU; then write back in place ------------
-// A fragments are software-pipelined in half tiles (16 k-steps = 4 x ds_read_b128): the next half tile's
-// reads are issued before the current half tile's 32 MFMAs; sched_barrier keeps hipcc from hoisting every
-// read to the top (which spills at the 256-VGPR budget that two workgroups per CU allow).
-__device__ __forceinline__ void dense_layer(float* __restrict__ H, const float (&Wf)[2][32], int wave, int lane) {
-    const int c = lane & 15, q = lane >> 4;
-    const int kb = (q & 1) * 64 + (q >> 1) * 32;  // kbase = {0, 64, 32, 96}
-    f32x4 acc[5][2];
-#pragma unroll
-    for (int m = 0; m < 5; ++m) {
-        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const float* arow = H + c * LD + kb;
-    f32x4 cur[4], nxt[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cur[j] = *reinterpret_cast<const f32x4*>(arow + 4 * j);
-#pragma unroll
-    for (int ht = 0; ht < 10; ++ht) {          // half tile ht: rows 16*(ht/2).., k-steps 16*(ht&1)..
-        const int m = ht >> 1, h = ht & 1;
-        if (ht < 9) {
-            const float* nsrc = arow + 16 * ((ht + 1) >> 1) * LD + 16 * ((ht + 1) & 1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) nxt[j] = *reinterpret_cast<const f32x4*>(nsrc + 4 * j);
-        } else {                                 // last stage prefetches node 80's first half for the VALU row
-            const float* nsrc = H + 80 * LD + kb;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) nxt[j] = *reinterpret_cast<const f32x4*>(nsrc + 4 * j);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float av = cur[s >> 2][s & 3];
-            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wf[0][16 * h + s], acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wf[1][16 * h + s], acc[m][1], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
-    }
-    // node 80: each lane covers its quarter of K for its two columns, quarters combined by xor-shuffles
-    float r0 = 0.f, r1 = 0.f;
-    {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) nxt[j] = *reinterpret_cast<const f32x4*>(H + 80 * LD + kb + 16 + 4 * j);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                r0 = fmaf(cur[j][i], Wf[0][4 * j + i], r0);
-                r1 = fmaf(cur[j][i], Wf[1][4 * j + i], r1);
-            }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                r0 = fmaf(nxt[j][i], Wf[0][16 + 4 * j + i], r0);
-                r1 = fmaf(nxt[j][i], Wf[1][16 + 4 * j + i], r1);
-            }
-        r0 += __shfl_xor(r0, 16); r0 += __shfl_xor(r0, 32);
-        r1 += __shfl_xor(r1, 16); r1 += __shfl_xor(r1, 32);
-    }
-    __syncthreads();  // every wave has finished reading H
-#pragma unroll
-    for (int m = 0; m < 5; ++m)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) H[(16 * m + 4 * q + i) * LD + 32 * wave + 16 * j + c] = acc[m][j][i];
-    if (q == 0) {
-        H[80 * LD + 32 * wave + c] = r0;
-        H[80 * LD + 32 * wave + 16 + c] = r1;
-    }
-    __syncthreads();
-}
-
-// ---- normalised neighbour gather + bias + ReLU, register-staged in place (POOL: reduce instead of write) ----
-template <bool POOL>
-__device__ __forceinline__ void gather_layer(TrunkSmem& sm, const float* __restrict__ bias_g, int tid,
-                                             float* __restrict__ pooled_out) {
-    const int cg = tid & 31, ng = tid >> 5;
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_g + 4 * cg);
-    f32x4 out[11];
-#pragma unroll
-    for (int i = 0; i < 11; ++i) {
-        const int t = ng + 8 * i;
-        if (t < 81) {
-            const float cs = sm.coef[0][t], cu = sm.coef[1][t], cd = sm.coef[2][t], cl = sm.coef[3][t], cr = sm.coef[4][t];
-            const int tu = t >= 9 ? t - 9 : t, td = t < 72 ? t + 9 : t, tl = t > 0 ? t - 1 : t, tr = t < 80 ? t + 1 : t;
-            const f32x4 hs = *reinterpret_cast<const f32x4*>(sm.H + t * LD + 4 * cg);
-            const f32x4 hu = *reinterpret_cast<const f32x4*>(sm.H + tu * LD + 4 * cg);
-            const f32x4 hd = *reinterpret_cast<const f32x4*>(sm.H + td * LD + 4 * cg);
-            const f32x4 hl = *reinterpret_cast<const f32x4*>(sm.H + tl * LD + 4 * cg);
-            const f32x4 hr = *reinterpret_cast<const f32x4*>(sm.H + tr * LD + 4 * cg);
-            f32x4 v = bias + cs * hs + cu * hu + cd * hd + cl * hl + cr * hr;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            out[i] = v;
-        } else {
-            out[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (POOL) {
-        f32x4 sum = out[0];
-#pragma unroll
-        for (int i = 1; i < 11; ++i) sum += out[i];
-        *reinterpret_cast<f32x4*>(&sm.part[ng][4 * cg]) = sum;
-        __syncthreads();
-        if (tid < HID) {
-            float s = 0.f;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) s += sm.part[g][tid];
-            pooled_out[tid] = s * (1.0f / 81.0f);
-        }
-    } else {
-        __syncthreads();  // all reads of the old image done
-#pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            const int t = ng + 8 * i;
-            if (t < 81) *reinterpret_cast<f32x4*>(sm.H + t * LD + 4 * cg) = out[i];
-        }
-        __syncthreads();
-    }
-}
+// Stripe row schedule shared by layer 1 and the stripe gathers: lane -> 4 columns (cg = lane & 7) of one row
+// per iteration (rs = lane >> 3).  Iterations 0..7 take rows it + 8*rs (0..63): with the 132-float row stride
+// the 16-lane ds_read_b128 groups then hit 16 distinct 16-byte bank slots.  Iterations 8..10 take rows
+// 64 + 8*(it-8) + rs (64..80; the last one only row 80).
+__device__ __forceinline__ int stripe_row(int it, int rs) { return it < 8 ? it + 8 * rs : 64 + 8 * (it - 8) + rs; }
+constexpr int STRIPE_ITERS = 11;
 
 // B fragments of W^T for this wave from the fragment-ordered copy: Wf[j][s] = W^T[kb + s][32*wave + 16*j + c].
 // 16 fully coalesced dwordx4 loads (1 KiB per wave-instruction) off one scalar base + one lane offset.
@@ -251,94 +143,317 @@ __device__ __forceinline__ void load_wfrag(float (&Wf)[2][32], const float* __re
         }
 }
 
+// ---- MFMA phase of one GCN layer: XW[0..79][stripe] = H[0..79][:] x W[:, stripe]  (PyG order: linear first).
+// Wave `wave` owns the 32-column stripe [32*wave, 32*wave+32) for ALL rows; its A operand is the whole image,
+// read as plain ds_read_b128 (no VALU in the MFMA stream).  Node 80 is done on VALU by the same lanes.
+// Half tiles (16 k-steps = 4 x ds_read_b128) are double-buffered; sched_barrier pins the read/MFMA order.
+__device__ __forceinline__ void stripe_matmul(const float* __restrict__ H, const float (&Wf)[2][32], int lane,
+                                              f32x4 (&acc)[5][2], float& r0, float& r1) {
+    const int c = lane & 15, q = lane >> 4;
+    const int kb = (q & 1) * 64 + (q >> 1) * 32;  // kbase = {0, 64, 32, 96}
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float* arow = H + c * LD + kb;
+    f32x4 cur[4], nxt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cur[j] = *reinterpret_cast<const f32x4*>(arow + 4 * j);
+#pragma unroll
+    for (int ht = 0; ht < 10; ++ht) {          // half tile ht: rows 16*(ht/2).., k-steps 16*(ht&1)..
+        const int m = ht >> 1, h = ht & 1;
+        const float* nsrc = (ht < 9) ? arow + 16 * ((ht + 1) >> 1) * LD + 16 * ((ht + 1) & 1) : H + 80 * LD + kb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nxt[j] = *reinterpret_cast<const f32x4*>(nsrc + 4 * j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float av = cur[s >> 2][s & 3];
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wf[0][16 * h + s], acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wf[1][16 * h + s], acc[m][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+    }
+    // node 80: each lane covers its quarter of K for its two columns, quarters combined by xor-shuffles
+    r0 = 0.f; r1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nxt[j] = *reinterpret_cast<const f32x4*>(H + 80 * LD + kb + 16 + 4 * j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r0 = fmaf(cur[j][i], Wf[0][4 * j + i], r0);
+            r1 = fmaf(cur[j][i], Wf[1][4 * j + i], r1);
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r0 = fmaf(nxt[j][i], Wf[0][16 + 4 * j + i], r0);
+            r1 = fmaf(nxt[j][i], Wf[1][16 + 4 * j + i], r1);
+        }
+    r0 += __shfl_xor(r0, 16); r0 += __shfl_xor(r0, 32);
+    r1 += __shfl_xor(r1, 16); r1 += __shfl_xor(r1, 32);
+}
+
+// ---- stripe epilogue: the wave parks its XW stripe in its own columns of H (the image is dead after the
+// barrier), then gathers it back with the normalised neighbour coefficients (= PyG's scatter-add on this
+// fixed-degree graph), + bias, ReLU.  Only this wave touches these columns, so ordering is wave-local.
+// LAST: mean-pool instead of writing back.
+template <bool LAST>
+__device__ __forceinline__ void stripe_gather(TrunkSmem& sm, const f32x4 (&acc)[5][2], float r0, float r1,
+                                              const float* __restrict__ bias_g, int wave, int lane,
+                                              float* __restrict__ pooled_out) {
+    {
+        const int c = lane & 15, q = lane >> 4;
+        float* w = sm.H + (4 * q) * LD + 32 * wave + c;
+#pragma unroll
+        for (int m = 0; m < 5; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w[(16 * m + i) * LD] = acc[m][0][i];
+                w[(16 * m + i) * LD + 16] = acc[m][1][i];
+            }
+        if (q == 0) {
+            sm.H[80 * LD + 32 * wave + c] = r0;
+            sm.H[80 * LD + 32 * wave + 16 + c] = r1;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int cg = lane & 7, rs = lane >> 3;
+    const int colb = 32 * wave + 4 * cg;
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_g + colb);
+    f32x4 out[STRIPE_ITERS];
+    // Row r's neighbours sit at fixed row offsets (-9, +9, -1, +1); off-board ones are clamped to r itself (their
+    // coefficient is 0).  With the schedule of stripe_row() every clamp is known at compile time except
+    // "up" in iterations 0..7 (only the rs == 0 lanes have r < 9), which is one per-lane offset.
+    const float* p1 = sm.H + colb + rs * 8 * LD;          // iteration it < 8: row it + 8*rs
+    const float* p2 = sm.H + colb + (64 + rs) * LD;       // iteration 8, 9: rows 64+rs, 72+rs
+    const float* k1 = &sm.coef[8 * rs][0];
+    const float* k2 = &sm.coef[64 + rs][0];
+    const int offU1 = rs == 0 ? 0 : -9 * LD;
+#pragma unroll
+    for (int it = 0; it < STRIPE_ITERS; ++it) {
+        const float *ps, *pu, *pd, *pl, *pr, *pk;
+        if (it < 8) {
+            ps = p1 + it * LD; pk = k1 + it * 8;
+            pu = ps + offU1; pd = ps + 9 * LD; pr = ps + LD;
+            pl = (it == 0) ? (rs == 0 ? ps : ps - LD) : ps - LD;
+        } else if (it == 8) {
+            ps = p2; pk = k2; pu = ps - 9 * LD; pd = ps + 9 * LD; pl = ps - LD; pr = ps + LD;
+        } else if (it == 9) {
+            ps = p2 + 8 * LD; pk = k2 + 64; pu = ps - 9 * LD; pd = ps; pl = ps - LD; pr = ps + LD;
+        } else {                                             // row 80 (every lane computes it; only rs == 0 is used)
+            ps = sm.H + colb + 80 * LD; pk = &sm.coef[80][0]; pu = ps - 9 * LD; pd = ps; pl = ps - LD; pr = ps;
+        }
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(pk);
+        const float kr = pk[4];
+        const f32x4 hs = *reinterpret_cast<const f32x4*>(ps);
+        const f32x4 hu = *reinterpret_cast<const f32x4*>(pu);
+        const f32x4 hd = *reinterpret_cast<const f32x4*>(pd);
+        const f32x4 hl = *reinterpret_cast<const f32x4*>(pl);
+        const f32x4 hr = *reinterpret_cast<const f32x4*>(pr);
+        f32x4 v = bias + k4[0] * hs + k4[1] * hu + k4[2] * hd + k4[3] * hl + kr * hr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        out[it] = v;
+        if (it & 1) __builtin_amdgcn_sched_barrier(0);   // two iterations' reads (14) in flight, not all 77
+    }
+    if (!LAST) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < STRIPE_ITERS; ++it) {
+            const int r = stripe_row(it, rs);
+            if (r < 81) *reinterpret_cast<f32x4*>(sm.H + r * LD + colb) = out[it];
+        }
+    } else {
+        f32x4 sum = out[0];
+#pragma unroll
+        for (int it = 1; it < STRIPE_ITERS - 1; ++it) sum += out[it];
+        if (rs == 0) sum += out[STRIPE_ITERS - 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = sum[e];
+            x += __shfl_xor(x, 8); x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+            sum[e] = x * (1.0f / 81.0f);
+        }
+        if (rs == 0) *reinterpret_cast<f32x4*>(pooled_out + colb) = sum;
+    }
+}
+
 // RESIDENT = true : one workgroup per CU (512-VGPR budget), both layers' fragments live in registers for the
 //                   whole kernel -> zero per-board weight traffic, but no cross-workgroup phase overlap.
 // RESIDENT = false: two workgroups per CU (256 VGPRs); each layer's fragments are re-fetched per board from
 //                   L2 (128 KB per board per workgroup), issued one phase ahead of use.
-template <bool RESIDENT>
-__global__ __launch_bounds__(256, RESIDENT ? 1 : 2) void gcn_trunk_boards_kernel(const void* __restrict__ states, int fmt,
+template <bool RESIDENT, int WGS_PER_CU>
+__global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_kernel(const void* __restrict__ states, int fmt,
                                                                                    int B, const float* __restrict__ pk,
                                                                                    float* __restrict__ pooled,
                                                                                    const uint8_t* __restrict__ active) {
     constexpr int N = 9, V = 81, S = 8;
     __shared__ TrunkSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 15, q = lane >> 4;
-    const int kb = (q & 1) * 64 + (q >> 1) * 32;
-    const int cg = tid & 31, ng = tid >> 5;
 
     float W2f[2][32], W3f[2][32];
     if (RESIDENT) {
         load_wfrag(W2f, pk + PackedLayout::WF2, wave, lane);
         load_wfrag(W3f, pk + PackedLayout::WF3, wave, lane);
     }
+    // Raw state prefetch: the record's dwords are loaded one board ahead and only unpacked at setup time, so
+    // the global-load latency hides under the previous board's layers (18 dwords for state72, 6 for QState).
+    const int ndw = fmt == 0 ? 18 : 6;
+    auto fetch_raw = [&](uint32_t (&raw)[18], int bb) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(states) + (size_t)bb * ndw;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) raw[i] = (i < ndw) ? src[i] : 0u;
+    };
+    auto unpack_raw = [&](const uint32_t (&raw)[18]) -> QState {
+        QState s;
+        if (fmt == 0) {
+            uint64_t h = 0, v = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                h |= (uint64_t)gather_bit0_x4(raw[1 + i]) << (4 * i);
+                v |= (uint64_t)gather_bit0_x4(raw[1 + i] >> 1) << (4 * i);
+            }
+            s.hw = h; s.vw = v;
+            s.ppos = (uint8_t)(raw[0] & 0xff); s.pwl = (uint8_t)((raw[0] >> 8) & 0xff);
+            s.epos = (uint8_t)((raw[0] >> 16) & 0xff); s.ewl = (uint8_t)(raw[0] >> 24);
+            s.plies = (uint16_t)(raw[17] & 0xffff);
+        } else {
+            s.hw = (uint64_t)raw[0] | ((uint64_t)raw[1] << 32);
+            s.vw = (uint64_t)raw[2] | ((uint64_t)raw[3] << 32);
+            s.ppos = (uint8_t)(raw[4] & 0xff); s.pwl = (uint8_t)((raw[4] >> 8) & 0xff);
+            s.epos = (uint8_t)((raw[4] >> 16) & 0xff); s.ewl = (uint8_t)(raw[4] >> 24);
+            s.plies = (uint16_t)(raw[5] & 0xffff);
+        }
+        s.pad = 0;
+        return s;
+    };
+    int b = blockIdx.x;
+    while (b < B && active && !active[b]) b += gridDim.x;
+    uint32_t raw[18];
+    if (b < B && tid < V) fetch_raw(raw, b);
 
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        if (active && !active[b]) continue;   // uniform per workgroup
-        // ---- setup: features + gather coefficients
+    AQG_STAMP_DECL
+    while (b < B) {
+        AQG_STAMP_AT(7)
+        // ---- setup step 1: node features + this tile's open-edge bits
         if (tid < V) {
-            const QState s = load_state(states, fmt, b);
+            const QState s = unpack_raw(raw);
             const int t = tid, x = t / N, y = t % N;
-            const int ob = tile_open_bits<N>(s.hw, s.vw, t);
-            const float di = dinv_of_bits(ob);
-            sm.coef[0][t] = di * di;
-            sm.coef[1][t] = (ob & 1) ? di * dinv_of_bits(tile_open_bits<N>(s.hw, s.vw, t - N)) : 0.f;
-            sm.coef[2][t] = (ob & 2) ? di * dinv_of_bits(tile_open_bits<N>(s.hw, s.vw, t + N)) : 0.f;
-            sm.coef[3][t] = (ob & 4) ? di * dinv_of_bits(tile_open_bits<N>(s.hw, s.vw, t - 1)) : 0.f;
-            sm.coef[4][t] = (ob & 8) ? di * dinv_of_bits(tile_open_bits<N>(s.hw, s.vw, t + 1)) : 0.f;
-            float* xr = sm.X0 + t * FPAD;
+            sm.obits[t] = tile_open_bits<N>(s.hw, s.vw, t);
             const bool slot_ok = (x < S) && (y < S);
             const int slot = x * S + y;
-            xr[0] = (t == s.ppos) ? 1.f : 0.f;
-            xr[1] = (float)s.pwl;
-            xr[2] = (t == s.epos) ? 1.f : 0.f;      // enemy's own frame (pv_network_cnn.py:101)
-            xr[3] = (float)s.ewl;
-            xr[4] = (slot_ok && ((s.hw >> slot) & 1)) ? 1.f : 0.f;
-            xr[5] = (slot_ok && ((s.vw >> slot) & 1)) ? 1.f : 0.f;
-            xr[6] = 0.f; xr[7] = 0.f;
+            f32x4 xa, xb;
+            xa[0] = (t == s.ppos) ? 1.f : 0.f;
+            xa[1] = (float)s.pwl;
+            xa[2] = (t == s.epos) ? 1.f : 0.f;      // enemy's own frame (pv_network_cnn.py:101)
+            xa[3] = (float)s.ewl;
+            xb[0] = (slot_ok && ((s.hw >> slot) & 1)) ? 1.f : 0.f;
+            xb[1] = (slot_ok && ((s.vw >> slot) & 1)) ? 1.f : 0.f;
+            xb[2] = 0.f; xb[3] = 0.f;
+            *reinterpret_cast<f32x4*>(sm.X0 + t * FPAD) = xa;
+            *reinterpret_cast<f32x4*>(sm.X0 + t * FPAD + 4) = xb;
         }
+        // prefetch the next board's raw record (lands under this board's layers)
+        int bn = b + gridDim.x;
+        while (bn < B && active && !active[bn]) bn += gridDim.x;
+        if (bn < B && tid < V) fetch_raw(raw, bn);
         if (!RESIDENT) load_wfrag(W2f, pk + PackedLayout::WF2, wave, lane);   // lands under layer 1
         __syncthreads();
-        // ---- layer 1: gather the 6 features, then 6 -> 128, bias, ReLU (weights re-read per board: L1/L2 hits)
-        float w1[4][6];
+        AQG_STAMP_AT(0)
+        // ---- setup step 2 + layer 1a: sym-norm coefficients from the neighbours' degrees, AX = A_hat * X0
+        if (tid < V) {
+            const int t = tid;
+            const int ob = sm.obits[t];
+            const int tu = t >= 9 ? t - 9 : t, td = t < 72 ? t + 9 : t, tl = t > 0 ? t - 1 : t, tr = t < 80 ? t + 1 : t;
+            const float di = dinv_of_bits(ob);
+            f32x4 k4;
+            k4[0] = di * di;
+            k4[1] = (ob & 1) ? di * dinv_of_bits(sm.obits[tu]) : 0.f;
+            k4[2] = (ob & 2) ? di * dinv_of_bits(sm.obits[td]) : 0.f;
+            k4[3] = (ob & 4) ? di * dinv_of_bits(sm.obits[tl]) : 0.f;
+            const float kr = (ob & 8) ? di * dinv_of_bits(sm.obits[tr]) : 0.f;
+            *reinterpret_cast<f32x4*>(&sm.coef[t][0]) = k4;
+            sm.coef[t][4] = kr;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(pk + PackedLayout::W1 + (4 * cg + e) * FPAD);
-            const float2 hi = *reinterpret_cast<const float2*>(pk + PackedLayout::W1 + (4 * cg + e) * FPAD + 4);
-            w1[e][0] = lo[0]; w1[e][1] = lo[1]; w1[e][2] = lo[2]; w1[e][3] = lo[3]; w1[e][4] = hi.x; w1[e][5] = hi.y;
-        }
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(pk + PackedLayout::B1 + 4 * cg);
-#pragma unroll 1
-        for (int i = 0; i < 11; ++i) {
-            const int t = ng + 8 * i;
-            if (t < V) {
-                const float cs = sm.coef[0][t], cu = sm.coef[1][t], cd = sm.coef[2][t], cl = sm.coef[3][t], cr = sm.coef[4][t];
-                const int tu = t >= 9 ? t - 9 : t, td = t < 72 ? t + 9 : t, tl = t > 0 ? t - 1 : t, tr = t < 80 ? t + 1 : t;
-                float ax[6];
-#pragma unroll
-                for (int f = 0; f < 6; ++f)
-                    ax[f] = cs * sm.X0[t * FPAD + f] + cu * sm.X0[tu * FPAD + f] + cd * sm.X0[td * FPAD + f] +
-                            cl * sm.X0[tl * FPAD + f] + cr * sm.X0[tr * FPAD + f];
-                f32x4 v = b1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                    for (int f = 0; f < 6; ++f) v[e] = fmaf(ax[f], w1[e][f], v[e]);
-                    v[e] = fmaxf(v[e], 0.f);
-                }
-                *reinterpret_cast<f32x4*>(sm.H + t * LD + 4 * cg) = v;
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = k4[0] * *reinterpret_cast<const f32x4*>(sm.X0 + t * FPAD + 4 * h) +
+                                k4[1] * *reinterpret_cast<const f32x4*>(sm.X0 + tu * FPAD + 4 * h) +
+                                k4[2] * *reinterpret_cast<const f32x4*>(sm.X0 + td * FPAD + 4 * h) +
+                                k4[3] * *reinterpret_cast<const f32x4*>(sm.X0 + tl * FPAD + 4 * h) +
+                                kr * *reinterpret_cast<const f32x4*>(sm.X0 + tr * FPAD + 4 * h);
+                *reinterpret_cast<f32x4*>(sm.AX + t * FPAD + 4 * h) = v;
             }
         }
         __syncthreads();
+        AQG_STAMP_AT(1)
+        // ---- layer 1b: H1[r][cols] = ReLU(b1 + AX[r] . W1[cols]) on this wave's stripe (4 columns x 1 row per lane-iteration)
+        {
+            const int cg = lane & 7, rs = lane >> 3;
+            const int colb = 32 * wave + 4 * cg;
+            float w1[4][6];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(pk + PackedLayout::W1 + (colb + e) * FPAD);
+                const float2 hi = *reinterpret_cast<const float2*>(pk + PackedLayout::W1 + (colb + e) * FPAD + 4);
+                w1[e][0] = lo[0]; w1[e][1] = lo[1]; w1[e][2] = lo[2]; w1[e][3] = lo[3]; w1[e][4] = hi.x; w1[e][5] = hi.y;
+            }
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(pk + PackedLayout::B1 + colb);
+#pragma unroll
+            for (int it = 0; it < STRIPE_ITERS; ++it) {
+                const int r = stripe_row(it, rs);
+                if (r < V) {
+                    const f32x4 xa = *reinterpret_cast<const f32x4*>(sm.AX + r * FPAD);
+                    const float2 xb = *reinterpret_cast<const float2*>(sm.AX + r * FPAD + 4);
+                    f32x4 v = b1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = v[e];
+                        a = fmaf(xa[0], w1[e][0], a); a = fmaf(xa[1], w1[e][1], a); a = fmaf(xa[2], w1[e][2], a);
+                        a = fmaf(xa[3], w1[e][3], a); a = fmaf(xb.x, w1[e][4], a); a = fmaf(xb.y, w1[e][5], a);
+                        v[e] = fmaxf(a, 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(sm.H + r * LD + colb) = v;
+                }
+                if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        AQG_STAMP_AT(2)
         // ---- layer 2
-        dense_layer(sm.H, W2f, wave, lane);
-        if (!RESIDENT) load_wfrag(W3f, pk + PackedLayout::WF3, wave, lane);   // lands under the layer-2 gather
-        gather_layer<false>(sm, pk + PackedLayout::B2, tid, nullptr);
+        f32x4 acc[5][2];
+        float r0, r1;
+        stripe_matmul(sm.H, W2f, lane, acc, r0, r1);
+        if (!RESIDENT) load_wfrag(W3f, pk + PackedLayout::WF3, wave, lane);   // lands under the layer-2 epilogue
+        __syncthreads();                       // every wave has finished reading the image
+        AQG_STAMP_AT(3)
+        stripe_gather<false>(sm, acc, r0, r1, pk + PackedLayout::B2, wave, lane, nullptr);
+        __syncthreads();
+        AQG_STAMP_AT(4)
         // ---- layer 3 + mean pool
-        dense_layer(sm.H, W3f, wave, lane);
-        gather_layer<true>(sm, pk + PackedLayout::B3, tid, pooled + (size_t)b * HID);
-        __syncthreads();  // part[] / coef / X0 reused by the next board
+        stripe_matmul(sm.H, W3f, lane, acc, r0, r1);
+        __syncthreads();
+        AQG_STAMP_AT(5)
+        stripe_gather<true>(sm, acc, r0, r1, pk + PackedLayout::B3, wave, lane, pooled + (size_t)b * HID);
+        __syncthreads();                       // coef / image are rewritten by the next board's setup
+        AQG_STAMP_AT(6)
+#ifdef AQG_STAMP
+        ++st_n;
+#endif
+        b = bn;
     }
+#ifdef AQG_STAMP
+    if (blockIdx.x == 0 && tid == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(pooled + (size_t)B * HID);
+        for (int i = 0; i < 8; ++i) o[i] = st_sum[i];
+        o[8] = (unsigned long long)st_n;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -445,10 +560,13 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     // persistent grid: 256 CUs x resident workgroups per CU, grid-stride over boards
     if (g_trunk_variant == 0) {
         int grid = B < 256 ? B : 256;
-        hipLaunchKernelGGL(gcn_trunk_boards_kernel<true>, dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
-    } else {
+        hipLaunchKernelGGL((gcn_trunk_boards_kernel<true, 1>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
+    } else if (g_trunk_variant == 1) {
         int grid = B < 512 ? B : 512;
-        hipLaunchKernelGGL(gcn_trunk_boards_kernel<false>, dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
+        hipLaunchKernelGGL((gcn_trunk_boards_kernel<false, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
+    } else {
+        int grid = B < 768 ? B : 768;
+        hipLaunchKernelGGL((gcn_trunk_boards_kernel<false, 3>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
     }
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;
     if (!logits && !policy && !value_pre && !value) return 0;   // trunk only (bench: time the dominant kernel alone)

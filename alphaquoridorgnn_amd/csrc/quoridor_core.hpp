@@ -48,17 +48,27 @@ struct QState {
 };
 static_assert(sizeof(QState) == 24, "QState must be 24 bytes");
 
+// 4 wall bytes (one u32) -> 4 H bits and 4 V bits: bit0 / bit1 of every byte gathered by a multiply
+QHD uint32_t gather_bit0_x4(uint32_t x) { return (((x & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; }
+
 QHD QState unpack72(const uint8_t* r) {
+    // 18 aligned dword loads instead of 72 byte loads (records are 72-byte strided, 4-byte aligned)
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(r);
     QState s;
     uint64_t h = 0, v = 0;
-    for (int i = 0; i < 64; ++i) {
-        uint8_t w = r[4 + i];
-        h |= (uint64_t)(w == 1) << i;
-        v |= (uint64_t)(w == 2) << i;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t x = w[1 + i];
+        h |= (uint64_t)gather_bit0_x4(x) << (4 * i);
+        v |= (uint64_t)gather_bit0_x4(x >> 1) << (4 * i);
     }
     s.hw = h; s.vw = v;
-    s.ppos = r[0]; s.pwl = r[1]; s.epos = r[2]; s.ewl = r[3];
-    s.plies = (uint16_t)(r[68] | (r[69] << 8));
+    const uint32_t hd = w[0], tl = w[17];
+    s.ppos = (uint8_t)(hd & 0xff); s.pwl = (uint8_t)((hd >> 8) & 0xff);
+    s.epos = (uint8_t)((hd >> 16) & 0xff); s.ewl = (uint8_t)(hd >> 24);
+    s.plies = (uint16_t)(tl & 0xffff);
     s.pad = 0;
     return s;
 }

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Diagnostic: build the trunk with -DAQG_STAMP and print the share of cycles per phase (workgroup 0, wave 0).
+Never quote this build's run time -- read its SHARES (guide: in-kernel stamps)."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+so = "/tmp/libaqgnn_hip_stamp.so"
+src = os.path.join(ROOT, "alphaquoridorgnn_amd", "csrc")
+subprocess.check_call(f"cd {src} && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DAQG_STAMP "
+                      f"legal_mask.hip gcn_forward.hip mcts.hip capi.hip -o {so}", shell=True)
+os.environ["AQG_LIB_PATH"] = so
+import torch
+from alphaquoridorgnn_amd import _lib
+from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+from tools.microbench import synth_states
+dev = _lib.require_gpu("cuda:0"); lib = _lib.load()
+model = GNNNetwork().to(dev).eval(); pk = model.packed_weights(dev)
+B = 65536
+st = synth_states(B)
+names = ["setup", "L1a gather6", "L1b 6->128", "L2 mfma", "L2 stripe gather", "L3 mfma", "L3 gather+pool", "loop top"]
+for v in (0, 1):
+    _lib.set_option("trunk_variant", v)
+    pooled = torch.zeros((B + 1, 128), device=dev)
+    for _ in range(3):
+        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, _lib.stream_ptr(dev)), "t")
+    torch.cuda.synchronize()
+    raw = pooled[B].view(torch.int64)[:9].cpu().tolist()
+    n = raw[8]; tot = sum(raw[:8])
+    print(f"variant {v}: boards by WG0 = {n}, cycles/board (s_memtime @100MHz units?) = {tot / max(n,1):.1f}")
+    for nm, c in zip(names, raw[:8]):
+        print(f"   {nm:18s} {c / max(n,1):10.1f}  {100.0 * c / tot:5.1f}%")
