@@ -29,7 +29,7 @@ class EngineStruct(_c.Structure):
                               "game_active", "game_plies", "game_result",
                               "legal_order", "legal_count", "pooled", "policy", "value",
                               "hist_state72", "hist_visits", "hist_action",
-                              "counters", "packed_weights")]
+                              "counters", "stat_leaf_evals", "stat_terminal_sims", "packed_weights")]
     )
 
 
@@ -37,6 +37,7 @@ SIGNATURES = {
     "aqg_abi_version": (_c.c_int, []),
     "aqg_last_error": (_c.c_char_p, []),
     "aqg_set_option": (_c.c_int, [_c.c_char_p, _c.c_int]),
+    "aqg_profile_collect": (_c.c_int, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_longlong), _c.POINTER(_c.c_longlong), _c.c_int]),
     "aqg_legal_actions": (_c.c_int, [_c.c_int, _vp, _c.c_int, _vp, _vp, _vp, _vp]),
     "aqg_state_next": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_int, _vp, _vp]),
     "aqg_state_status": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp]),
@@ -104,3 +105,10 @@ def require_gpu(device=None):
 
 def set_option(name, value):
     check(load().aqg_set_option(name.encode(), int(value)), f"aqg_set_option({name})")
+
+
+def profile_collect(reset=False):
+    """(total_ms, launches, boards) of the profiled trunk launches so far (see aqg_profile_collect)."""
+    ms, n, b = _c.c_double(0), _c.c_longlong(0), _c.c_longlong(0)
+    check(load().aqg_profile_collect(_c.byref(ms), _c.byref(n), _c.byref(b), 1 if reset else 0), "aqg_profile_collect")
+    return ms.value, n.value, b.value

@@ -5,6 +5,8 @@
 namespace aqg {
 thread_local char g_err[512] = "";
 extern int g_trunk_variant;
+extern int g_profile_trunk;
+int profile_collect(double* total_ms, long long* launches, long long* boards, int reset);
 
 size_t packed_floats();
 int pack_weights_host(int N, const float* const* t, float* out);
@@ -34,7 +36,12 @@ const char* aqg_last_error(void) { return g_err; }
 
 int aqg_set_option(const char* name, int value) {
     if (name && !strcmp(name, "trunk_variant")) { if (value < 0 || value > 2) return fail("trunk_variant must be 0, 1 or 2"); g_trunk_variant = value; return 0; }
+    if (name && !strcmp(name, "profile_trunk")) { g_profile_trunk = value ? 1 : 0; return 0; }
     return fail("unknown option", name ? name : "(null)");
+}
+
+int aqg_profile_collect(double* total_ms_host, long long* launches_host, long long* boards_host, int reset) {
+    return profile_collect(total_ms_host, launches_host, boards_host, reset);
 }
 
 int aqg_legal_actions(int board_size, const uint8_t* states72, int B, uint8_t* mask, uint8_t* order, int32_t* count,

@@ -18,6 +18,7 @@
 //
 // graph kernels: the same network on an arbitrary (x, CSR, graph_ptr) batch -- generic boundary path.
 #include "aqg_common.hpp"
+#include <vector>
 
 namespace aqg {
 
@@ -459,38 +460,53 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_kernel(const
 // ---------------------------------------------------------------------------------------------
 // heads: 16 boards per workgroup
 // ---------------------------------------------------------------------------------------------
-constexpr int HB = 16;
+constexpr int HB = 8;   // boards per workgroup: B = 2048 -> 256 workgroups, one per CU
 
+// Latency-bound small GEMMs: the weights stream from L2 (118 KB, shared by every workgroup), so the loop is built
+// for memory-level parallelism -- 16 independent coalesced weight loads in flight per thread -- and the 8 boards
+// of a workgroup sit transposed in LDS ([k][board]) so one k-step reads them with two broadcast ds_read_b128.
 __global__ __launch_bounds__(256) void gcn_heads_kernel(const float* __restrict__ pooled, int B, int A,
                                                         const float* __restrict__ pk, float* __restrict__ logits,
                                                         float* __restrict__ policy, float* __restrict__ value_pre,
                                                         float* __restrict__ value, const uint8_t* __restrict__ active) {
-    __shared__ float g[HB][HID];
-    __shared__ float hid[HB][HID];
+    __shared__ alignas(16) float gT[HID][HB];          // pooled features, transposed
+    __shared__ alignas(16) float part[2][HID][HB];     // hidden-layer partial sums of the two k halves
+    __shared__ alignas(16) float hidT[HID][HB];        // hidden activations (0..63 policy, 64..127 value), transposed
     __shared__ float lg[HB][APAD];
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * HB;
     const int nb = min(HB, B - b0);
     for (int i = tid; i < HB * HID; i += 256) {
         const int r = i / HID, k = i % HID;
-        g[r][k] = (r < nb) ? pooled[(size_t)(b0 + r) * HID + k] : 0.f;
+        gT[k][r] = (r < nb) ? pooled[(size_t)(b0 + r) * HID + k] : 0.f;
     }
     __syncthreads();
-    {   // hidden layer of both heads: unit u (0..63 policy, 64..127 value), 8 boards per thread
-        const int u = tid & 127, bh = tid >> 7;
-        float acc[8];
-        const float bias = pk[PackedLayout::HB1 + u];
+    {   // hidden layer of both heads: unit u, k half kh (64 k each), all 8 boards
+        const int u = tid & 127, kh = tid >> 7;
+        float acc[HB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = bias;
-        const float* w = pk + PackedLayout::HW1T + u;
-#pragma unroll 4
-        for (int k = 0; k < HID; ++k) {
-            const float wk = w[(size_t)k * HID];
+        for (int i = 0; i < HB; ++i) acc[i] = 0.f;
+        const float* w = pk + PackedLayout::HW1T + (size_t)(64 * kh) * HID + u;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = fmaf(g[8 * bh + i][k], wk, acc[i]);
+        for (int k0 = 0; k0 < 64; k0 += 16) {
+            float wk[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wk[j] = w[(size_t)(k0 + j) * HID];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(&gT[64 * kh + k0 + j][0]);
+                const f32x4 gb = *reinterpret_cast<const f32x4*>(&gT[64 * kh + k0 + j][4]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[i] = fmaf(ga[i], wk[j], acc[i]); acc[4 + i] = fmaf(gb[i], wk[j], acc[4 + i]); }
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) hid[8 * bh + i][u] = fmaxf(acc[i], 0.f);
+        *reinterpret_cast<f32x4*>(&part[kh][u][0]) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(&part[kh][u][4]) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+    }
+    __syncthreads();
+    for (int i = tid; i < HID * HB; i += 256) {
+        const int u = i / HB, r = i % HB;
+        hidT[u][r] = fmaxf(part[0][u][r] + part[1][u][r] + pk[PackedLayout::HB1 + u], 0.f);
     }
     __syncthreads();
     if (tid < A) {
@@ -499,27 +515,34 @@ __global__ __launch_bounds__(256) void gcn_heads_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < HB; ++i) acc[i] = bias;
         const float* w = pk + PackedLayout::PW2T + tid;
-#pragma unroll 4
-        for (int k = 0; k < HID / 2; ++k) {
-            const float wk = w[(size_t)k * APAD];
 #pragma unroll
-            for (int i = 0; i < HB; ++i) acc[i] = fmaf(hid[i][k], wk, acc[i]);
+        for (int k0 = 0; k0 < HID / 2; k0 += 16) {
+            float wk[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wk[j] = w[(size_t)(k0 + j) * APAD];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const f32x4 ha = *reinterpret_cast<const f32x4*>(&hidT[k0 + j][0]);
+                const f32x4 hb = *reinterpret_cast<const f32x4*>(&hidT[k0 + j][4]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[i] = fmaf(ha[i], wk[j], acc[i]); acc[4 + i] = fmaf(hb[i], wk[j], acc[4 + i]); }
+            }
         }
 #pragma unroll
         for (int i = 0; i < HB; ++i) lg[i][tid] = acc[i];
-    } else if (tid >= 240) {   // value head: one thread per board
-        const int i = tid - 240;
+    } else if (tid >= 248) {   // value head: one thread per board
+        const int i = tid - 248;
         float acc = pk[PackedLayout::VB2];
-        for (int k = 0; k < HID / 2; ++k) acc = fmaf(hid[i][HID / 2 + k], pk[PackedLayout::VW2 + k], acc);
+        for (int k = 0; k < HID / 2; ++k) acc = fmaf(hidT[HID / 2 + k][i], pk[PackedLayout::VW2 + k], acc);
         if (i < nb && !(active && !active[b0 + i])) {
             if (value_pre) value_pre[b0 + i] = acc;
             if (value) value[b0 + i] = tanhf(acc);
         }
     }
     __syncthreads();
-    // softmax: wave w handles boards 4w..4w+3
+    // softmax: wave w handles boards 2w, 2w+1
     const int lane = tid & 63, wave = tid >> 6;
-    for (int r = 4 * wave; r < 4 * wave + 4; ++r) {
+    for (int r = 2 * wave; r < 2 * wave + 2; ++r) {
         if (r >= nb) break;
         if (active && !active[b0 + r]) continue;
         float m = -INFINITY;
@@ -549,15 +572,52 @@ __global__ __launch_bounds__(256) void gcn_heads_kernel(const float* __restrict_
 
 int g_trunk_variant = 1;  // set by aqg_set_option("trunk_variant", v)
 
+// Optional launch profiling of the dominant kernel (aqg_set_option("profile_trunk", 1)): a HIP event pair is
+// recorded around every trunk launch on the launch stream; aqg_profile_collect() reads them back.
+int g_profile_trunk = 0;
+static std::vector<hipEvent_t> g_prof_events;
+static size_t g_prof_used = 0;
+static double g_prof_ms = 0.0;
+static long long g_prof_launches = 0;
+static long long g_prof_boards = 0;
+
+static hipEvent_t prof_event() {
+    if (g_prof_used == g_prof_events.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        g_prof_events.push_back(e);
+    }
+    return g_prof_events[g_prof_used++];
+}
+
+int profile_collect(double* total_ms, long long* launches, long long* boards, int reset) {
+    if (g_prof_used) {
+        if (hipEventSynchronize(g_prof_events[g_prof_used - 1]) != hipSuccess) return fail("hipEventSynchronize");
+        for (size_t i = 0; i + 1 < g_prof_used; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, g_prof_events[i], g_prof_events[i + 1]) != hipSuccess) return fail("hipEventElapsedTime");
+            g_prof_ms += ms;
+            ++g_prof_launches;
+        }
+        g_prof_used = 0;
+    }
+    if (total_ms) *total_ms = g_prof_ms;
+    if (launches) *launches = g_prof_launches;
+    if (boards) *boards = g_prof_boards;
+    if (reset) { g_prof_ms = 0.0; g_prof_launches = 0; g_prof_boards = 0; }
+    return 0;
+}
+
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
                               hipStream_t st) {
     if (N != 9) return fail("fused board trunk is built for 9x9; use aqg_gcn_forward_graph for other sizes");
     if (B <= 0) return 0;
     if (!pooled) return fail("pooled workspace is required");
-    if (N * N + 2 * (N - 1) * (N - 1) > 240) return fail("policy size exceeds 240");
+    if (N * N + 2 * (N - 1) * (N - 1) > 248) return fail("policy size exceeds 248");
     const int A = N * N + 2 * (N - 1) * (N - 1);
     // persistent grid: 256 CUs x resident workgroups per CU, grid-stride over boards
+    if (g_profile_trunk) { hipEventRecord(prof_event(), st); g_prof_boards += B; }
     if (g_trunk_variant == 0) {
         int grid = B < 256 ? B : 256;
         hipLaunchKernelGGL((gcn_trunk_boards_kernel<true, 1>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
@@ -568,6 +628,7 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
         int grid = B < 768 ? B : 768;
         hipLaunchKernelGGL((gcn_trunk_boards_kernel<false, 3>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
     }
+    if (g_profile_trunk) hipEventRecord(prof_event(), st);
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;
     if (!logits && !policy && !value_pre && !value) return 0;   // trunk only (bench: time the dominant kernel alone)
     hipLaunchKernelGGL(gcn_heads_kernel, dim3((B + HB - 1) / HB), dim3(256), 0, st, (const float*)pooled, B, A, packed,
@@ -639,7 +700,7 @@ int launch_gcn_forward_graph(int F, int A, const float* x, int num_nodes, const 
                              float* work0, float* work1, float* pooled, float* logits, float* policy, float* value_pre,
                              float* value, hipStream_t st) {
     if (F != 6) return fail("num_features must be 6 (NUM_FEATURES pv_network_gnn.py:17)");
-    if (A > APAD) return fail("policy size exceeds 256");
+    if (A > 248) return fail("policy size exceeds 248");
     if (num_nodes <= 0 || num_graphs <= 0) return 0;
     dim3 lg((num_nodes + 31) / 32), gg((num_nodes + 3) / 4);
     hipLaunchKernelGGL(graph_linear_kernel<true>, lg, dim3(256), 0, st, x, F, num_nodes, packed + PackedLayout::W1, work0);

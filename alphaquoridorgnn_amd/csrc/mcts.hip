@@ -43,6 +43,19 @@ struct GameCtx {
     size_t nb;  // node base of this game
 };
 
+// Backup (pv_mcts.py:36-42,:49-50,:62-64): every node on the path gets w += value, n += 1 with the sign flipping
+// per ply.  The path nodes are distinct, so lane d updates path[d] independently (one parallel step instead of a
+// serial chain of dependent global read-modify-writes); the sums are the same float64 additions.
+__device__ __forceinline__ void backup_path(const aqg_engine& e, size_t nb, const int* __restrict__ path, int depth,
+                                            double leaf_value, int lane) {
+    for (int d = lane; d <= depth; d += 64) {
+        const size_t idx = nb + path[d];
+        const double v = ((depth - d) & 1) ? -leaf_value : leaf_value;
+        e.node_w[idx] += v;
+        e.node_n[idx] += 1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // reset: every slot -> initial position (game_logic.py:25-40), active
 // ------------------------------------------------------------------------------------------------
@@ -65,6 +78,8 @@ __global__ void engine_reset_kernel(aqg_engine e) {
     e.game_result[g] = 0;
     e.node_count[g] = 0;
     e.leaf_flag[g] = 0;
+    e.stat_leaf_evals[g] = 0;
+    e.stat_terminal_sims[g] = 0;
 }
 
 __global__ void engine_set_roots_kernel(aqg_engine e, const uint8_t* __restrict__ roots72) {
@@ -106,6 +121,7 @@ __global__ __launch_bounds__(256) void engine_select_kernel(aqg_engine e) {
     int* path = e.path + (size_t)g * (e.sims + 2);
     QState s = load_state(e.root_state, 1, g);
     int node = 0, depth = 0;
+    int mynode = 0;                      // lane d keeps the path node at depth d (d < 64) in a register
     if (lane == 0) path[0] = 0;
     int terminal = 0;
     double value = 0.0;
@@ -156,17 +172,23 @@ __global__ __launch_bounds__(256) void engine_select_kernel(aqg_engine e) {
         s = next_state<N>(s, e.node_action[nb + node]);
         ++depth;
         if (lane == 0) path[depth] = node;
+        if (lane == (depth & 63) && depth < 64) mynode = node;
     }
     if (terminal) {
+        // backup (pv_mcts.py:36-42): lane d updates the node at depth d from its register copy; the (practically
+        // unreachable) part of a path deeper than 63 is finished by lane 0 from its own path[] stores
+        if (lane <= depth) {
+            const size_t idx = nb + mynode;
+            e.node_w[idx] += ((depth - lane) & 1) ? -value : value;
+            e.node_n[idx] += 1;
+        }
         if (lane == 0) {
-            double v = value;
-            for (int d = depth; d >= 0; --d) {                 // w += value; n += 1 along the path, sign flips per ply
+            e.stat_terminal_sims[g] += 1;
+            for (int d = 64; d <= depth; ++d) {
                 const size_t idx = nb + path[d];
-                e.node_w[idx] += v;
+                e.node_w[idx] += ((depth - d) & 1) ? -value : value;
                 e.node_n[idx] += 1;
-                v = -v;
             }
-            atomicAdd(&e.counters[4], 1);
         }
     } else if (lane == 0) {
         store_state(e.leaf_state, g, s);
@@ -271,20 +293,12 @@ __global__ __launch_bounds__(256) void engine_expand_backup_kernel(aqg_engine e)
             }
         }
     }
-    if (lane == 0) {
-        if (first + cnt <= e.node_cap && cnt > 0) {
-            e.node_kids[nb + leaf] = (uint32_t)first | ((uint32_t)cnt << 24);
-            e.node_count[g] = first + cnt;
-        }
-        double v = (double)e.value[g];                         // value.item() -> python float
-        for (int d = depth; d >= 0; --d) {
-            const size_t idx = nb + path[d];
-            e.node_w[idx] += v;
-            e.node_n[idx] += 1;
-            v = -v;
-        }
-        atomicAdd(&e.counters[3], 1);
+    if (lane == 0 && first + cnt <= e.node_cap && cnt > 0) {
+        e.node_kids[nb + leaf] = (uint32_t)first | ((uint32_t)cnt << 24);
+        e.node_count[g] = first + cnt;
     }
+    backup_path(e, nb, path, depth, (double)e.value[g], lane);   // value.item() -> python float
+    if (lane == 0) e.stat_leaf_evals[g] += 1;   // per-game slot: a shared counter would serialise 2048 atomics per step
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -64,6 +64,8 @@ class BatchedSelfPlay:
         t["hist_visits"] = z((G, hp, self.A), torch.int16)
         t["hist_action"] = z((G, hp), torch.uint8)
         t["counters"] = z((8,), torch.int32)
+        t["stat_leaf_evals"] = z((G,), torch.int32)
+        t["stat_terminal_sims"] = z((G,), torch.int32)
         if evaluator == "gnn":
             if model is None:
                 raise ValueError("evaluator='gnn' needs a model")
@@ -81,7 +83,7 @@ class BatchedSelfPlay:
         for name in ("node_p", "node_w", "node_n", "node_action", "node_kids", "node_count", "root_state", "path",
                      "path_len", "leaf_flag", "leaf_state", "game_active", "game_plies", "game_result", "legal_order",
                      "legal_count", "pooled", "policy", "value", "hist_state72", "hist_visits", "hist_action", "counters",
-                     "packed_weights"):
+                     "stat_leaf_evals", "stat_terminal_sims", "packed_weights"):
             setattr(e, name, t[name].data_ptr())
         self.record_history = record_history
         self.moves_done = 0
@@ -112,7 +114,9 @@ class BatchedSelfPlay:
 
     def counters(self):
         c = self.t["counters"].cpu().numpy()
-        return dict(active=int(c[0]), finished=int(c[1]), dead_ends=int(c[2]), leaf_evals=int(c[3]), terminal_sims=int(c[4]))
+        return dict(active=int(c[0]), finished=int(c[1]), dead_ends=int(c[2]),
+                    leaf_evals=int(self.t["stat_leaf_evals"].sum().item()),
+                    terminal_sims=int(self.t["stat_terminal_sims"].sum().item()))
 
     def play_generation(self, uniforms=None, check_every=4):
         """Play every slot to termination (one self_play generation's worth of games on this rank).

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play games/s (whole job) + GNN boards/s on MI355X, with roofline and CPU baseline.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run with one
+rank per GPU (RCCL).  One STEP = one self-play generation on every rank: `--games` concurrent 9x9 games per GPU
+(default 2048, BASELINE.json configs[2]) played to termination with PV-MCTS at `--sims` simulations per move
+(default 200) and the random-weight GNN as evaluator, followed by the generation's single exchange step -- the
+all-gather of the (s, pi, z) tuples over RCCL/xGMI (configs[3]).  Weak scaling: per-GPU work is fixed.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  gnn_forward  : configs[1] -- pv_network_gnn forward at B=4096 synthetic boards, boards/s (HIP events)
+  roofline     : the dominant kernel (gcn_trunk_boards_kernel) over the timed region: algorithmic FLOP of the
+                 boards it processed / its summed launch durations (HIP event pairs recorded around every launch on
+                 the launch stream inside the library), against the fp32 MFMA peak; the SURVEY 8(d) HBM figure
+                 (169,760 B/board against 8 TB/s) is reported beside it as hbm_frac
+  cpu_baseline : the oracle (CPU restatement, kind "port") on a bounded sample of the same workload, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+TRUNK_FLOP_PER_BOARD = 2 * 81 * 6 * 128 + 2 * (2 * 81 * 128 * 128)   # 5,432,832: the three GCN contractions
+FWD_FLOP_PER_BOARD = 5492480                                         # trunk + both heads
+HBM_BYTES_PER_BOARD = 169760                                         # layer-granular algorithmic bytes
+PEAK_F32_MFMA = 157.3e12                                             # MI355X_MICROARCH.md: f32-input MFMA
+PEAK_HBM = 8.0e12
+
+
+def cpu_baseline(sims, mean_plies, budget_s=15.0):
+    """Oracle (oracle/mcts.py + oracle/gnn.py fp64 + C rules) timed on the host: bounded sample of one game."""
+    from oracle import gnn as og, mcts as om, quoridor as oq
+    oq.lib()
+    model = og.OracleModel(og.init_params(0))
+    rng = np.random.RandomState(0)
+    state = oq.State(N=9)
+    t0 = time.time()
+    plies = 0
+    while time.time() - t0 < budget_s and not state.is_done():
+        scores = om.pv_mcts_policy(model, state, 1.0, sims)
+        legal = state.legal_actions()
+        state = state.next(legal[om.choice_index(scores, rng.random_sample())])
+        plies += 1
+    dt = time.time() - t0
+    sims_per_s = plies * sims / dt
+    return {"value": (plies / dt) / max(mean_plies, 1.0), "unit": "games/s", "cores": 1, "kind": "port",
+            "sims_per_s": sims_per_s,
+            "sample": f"first {plies} plies of one {sims}-sims/move game (numpy-fp64 GNN oracle + C rules oracle, 1 thread, "
+                      f"{dt:.1f} s); games/s = plies/s / {mean_plies:.1f} mean plies per game of the GPU run"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=2048, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=200, help="MCTS simulations per move")
+    ap.add_argument("--gnn-batch", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay, gather_history
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+    lib = _lib.load()                    # no HIP library -> hard failure, there is no fallback path
+
+    torch.manual_seed(0)                 # random-init weights of the reference architecture (synthetic; no checkpoints)
+    model = GNNNetwork().to(dev).eval()
+    eng = BatchedSelfPlay(model, num_games=args.games, sims=args.sims, seed=1000 + rank)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step(profile):
+        eng.reset()
+        ply = 0
+        while True:
+            eng.move()
+            ply += 1
+            if ply % 4 == 0 or ply >= eng.max_plies:
+                if profile:
+                    _lib.profile_collect()
+                if eng.counters()["active"] == 0 or ply >= eng.max_plies:
+                    break
+        st, vis, z = eng.history_tensors()
+        st, vis, z = gather_history(st, vis, z)       # the generation's one exchange step (RCCL all-gather)
+        return eng.counters(), int(st.shape[0])
+
+    for _ in range(args.warmup):
+        one_step(False)
+    _lib.set_option("profile_trunk", 1)
+    _lib.profile_collect(reset=True)
+    sync_all()
+    t0 = time.time()
+    games = positions = leaf_evals = 0
+    for _ in range(args.steps):
+        c, npos = one_step(True)
+        games += c["finished"]
+        leaf_evals += c["leaf_evals"]
+        positions = npos
+    sync_all()
+    elapsed = time.time() - t0
+    trunk_ms, trunk_launches, trunk_rows = _lib.profile_collect(reset=True)
+    _lib.set_option("profile_trunk", 0)
+
+    tt = torch.tensor([elapsed, float(games), float(leaf_evals)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+    total_games, total_evals = float(tt[1]), float(tt[2])
+    mean_plies = positions / max(total_games / max(args.steps, 1), 1.0)   # gathered positions of the last step / games per step
+
+    # ---- configs[1]: GNN forward, B = 4096 synthetic boards, HIP events on the launch stream (rank-local)
+    from tools.microbench import synth_states, time_ms
+    B = args.gnn_batch
+    boards = synth_states(B, seed=0, dev=dev)
+    pooled = torch.empty((B, 128), device=dev)
+    policy = torch.empty((B, 209), device=dev)
+    value = torch.empty((B,), device=dev)
+    pk = model.packed_weights(dev)
+
+    def fwd():
+        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(boards), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None,
+                                              _lib.ptr(value), _lib.stream_ptr(dev)), "fwd")
+    fwd_ms = time_ms(fwd, 200, warmup=20)
+
+    if rank == 0:
+        achieved = leaf_evals * TRUNK_FLOP_PER_BOARD / (trunk_ms * 1e-3) if trunk_ms > 0 else 0.0   # rank 0's launches
+        boards_per_s_kernel = leaf_evals / (trunk_ms * 1e-3) if trunk_ms > 0 else 0.0
+        out = {
+            "metric": "self-play games/sec, 9x9 Quoridor (PV-MCTS, GNN evaluator), whole job",
+            "value": total_games / elapsed,
+            "unit": "games/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]/[3]: one self-play generation per step -- concurrent 9x9 games per GPU "
+                                   "played to termination, lock-step PV-MCTS, random-weight GNN evaluator, then the all-gather of (s,pi,z)",
+                       "games_per_gpu": args.games, "sims_per_move": args.sims, "board": "9x9", "walls": 10, "plies_for_draw": 116,
+                       "temperature": 1.0, "c_puct": 1.25, "parallelism": f"games sharded over {world} rank(s), 1 all-gather per generation"},
+            "leaf_evals_per_s": total_evals / elapsed,
+            "sims_per_s": total_evals / elapsed,   # terminal simulations excluded
+            "mean_plies_per_game": mean_plies,
+            "positions_gathered_per_step": positions,
+            "gnn_forward": {"workload": f"BASELINE configs[1]: pv_network_gnn forward, batch={B} synthetic boards (trunk + heads)",
+                            "boards_per_s": B / (fwd_ms * 1e-3), "ms": fwd_ms,
+                            "mfma_frac": B / (fwd_ms * 1e-3) * FWD_FLOP_PER_BOARD / PEAK_F32_MFMA,
+                            "hbm_frac_survey_formula": B / (fwd_ms * 1e-3) * HBM_BYTES_PER_BOARD / PEAK_HBM},
+            "roofline": {"kernel": "gcn_trunk_boards_kernel", "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA, "traffic": None,
+                         "launches": trunk_launches, "avg_launch_us": trunk_ms / max(trunk_launches, 1) * 1e3,
+                         "boards_per_launch_avg": leaf_evals / max(trunk_launches, 1),
+                         "flop_per_board": TRUNK_FLOP_PER_BOARD,
+                         "hbm_frac_survey_formula": boards_per_s_kernel * HBM_BYTES_PER_BOARD / PEAK_HBM,
+                         "note": "fp32 parity path: the f32-input MFMA contraction is the binding roof (SURVEY 8d); activations "
+                                 "never leave LDS, so real HBM traffic is ~24 B in + 512 B out per board"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.sims, mean_plies)
+            out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

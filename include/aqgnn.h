@@ -35,6 +35,11 @@ int aqg_abi_version(void);
 const char* aqg_last_error(void);
 /* tuning knobs: "trunk_variant" 0 = weights resident in registers, 1 workgroup/CU; 1 = per-layer re-fetch, 2/CU */
 int aqg_set_option(const char* name, int value);
+/* Measurement aid (bench.py): with option "profile_trunk" = 1 a HIP event pair is recorded around every launch of the
+ * dominant kernel (the GCN trunk) on its launch stream.  This call waits for the last recorded event, accumulates
+ * the elapsed times and returns the running totals (HOST pointers; `boards` = sum of launch batch sizes incl.
+ * masked-out rows); reset != 0 clears the totals.  It is the only entry point that blocks the host. */
+int aqg_profile_collect(double* total_ms_host, long long* launches_host, long long* boards_host, int reset);
 
 /* ------------------------------------------------------------------ game rules (game_logic.py) */
 
@@ -121,8 +126,10 @@ typedef struct aqg_engine {
     /* history, per slot: [G, max_plies, ...] */
     uint8_t* hist_state72; uint16_t* hist_visits /* [G,max_plies,A] root child visit counts, dense by action */;
     uint8_t* hist_action /* [G,max_plies] */;
-    /* counters [8] i32: 0 active games, 1 finished games, 2 dead-end aborts, 3 leaf evals, 4 terminal sims */
+    /* counters [8] i32: 0 active games, 1 finished games, 2 dead-end aborts (updated once per move) */
     int32_t* counters;
+    /* per-game statistics [G] i32 (summed by the host): network evaluations, simulations that ended on a terminal node */
+    int32_t* stat_leaf_evals; int32_t* stat_terminal_sims;
     const float* packed_weights;
 } aqg_engine;
 
