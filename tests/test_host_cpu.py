@@ -1,0 +1,158 @@
+"""CPU tests (no GPU): host-side logic of the drop-in modules, the C-ABI surface of libaqgnn_hip.so (symbols only --
+no compute call is possible without a GPU), and the N>1 exchange step on gloo with world_size 2."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests import _util as U
+
+REPO = U.REPO
+
+
+def test_capi_exports_every_declared_symbol():
+    """Every function declared in include/aqgnn.h must be exported by the built library and bound by _lib.py."""
+    from alphaquoridorgnn_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "aqgnn.h")).read()
+    declared = set(re.findall(r"\b(aqg_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("aqg_engine")
+    assert len(declared) >= 15
+    lib = _lib.load()                     # must exist: built by __graft_entry__.build()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in aqgnn.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} not bound in _lib.SIGNATURES"
+    assert lib.aqg_abi_version() == _lib.ABI_VERSION
+    assert lib.aqg_gcn_packed_floats(9) > 64082          # all 64,082 parameters + padding + fragment copies
+    assert ctypes.sizeof(_lib.EngineStruct) == 9 * 4 + 2 * 4 + 4 + 26 * 8   # 11 scalars (+4 pad) + 26 pointers
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a GPU the hot path must fail loudly, never compute on the host."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.game_logic import State
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+    with pytest.raises(_lib.HipLibraryError):
+        State().legal_actions()
+    with pytest.raises(_lib.HipLibraryError):
+        GNNNetwork().predict(State(), "cpu")
+    for mod in ("game_logic", "pv_network_gnn", "pv_mcts", "self_play", "engine", "_lib"):
+        src = open(os.path.join(REPO, "alphaquoridorgnn_amd", mod + ".py")).read()
+        assert "import oracle" not in src and "from oracle" not in src, f"{mod} must not touch the oracle"
+
+
+def test_state_host_logic_matches_reference_vectors():
+    """State bookkeeping (next / rotate / terminal flags / to_array) is host Python like the reference; check it
+    against the reference-generated walk."""
+    from alphaquoridorgnn_amd.game_logic import State, pack_state72
+    g = U.golden("walk_9x9.npz")
+    for i in range(0, 3000, 7):
+        r = g["states"][i]
+        s = State(player=[int(r[0]), int(r[1])], enemy=[int(r[2]), int(r[3])], walls=[int(x) for x in r[4:68]],
+                  plies_played=int(r[68]) | (int(r[69]) << 8))
+        assert np.array_equal(s.record(), r)
+        assert ((1 if s.is_lose() else 0) | (2 if s.is_draw() else 0)) == g["status"][i]
+        a = int(g["actions"][i])
+        if a >= 0:
+            n = s.next(a)
+            assert np.array_equal(n.record(), g["next_states"][i])
+            assert s.to_array() == [[int(r[0]), int(r[1])], [int(r[2]), int(r[3])], [int(x) for x in r[4:68]]]
+    with pytest.raises(ValueError):
+        State(board_size=6)
+    s0 = State()
+    assert s0.player == [76, 10] and s0.enemy == [76, 10] and s0.is_first_player() and not s0.is_done()
+
+
+def test_module_surface_matches_reference_names():
+    import alphaquoridorgnn_amd.pv_mcts as pm
+    import alphaquoridorgnn_amd.self_play as sp
+    import alphaquoridorgnn_amd.pv_network_gnn as pg
+    import alphaquoridorgnn_amd.constants as c
+    assert pm.PV_EVALUATE_COUNT == 50 and callable(pm.pv_mcts_policy) and callable(pm.pv_mcts_action)
+    assert pm.boltzman([1, 3], 1.0) == [0.25, 0.75]
+    assert sp.SP_GAME_COUNT == 50 and sp.SP_TEMPERATURE == 1.0
+    assert (pg.NUM_FEATURES, pg.HIDDEN_DIM, pg.NUM_GCN_LAYERS, pg.POLICY_OUTPUT_SIZE) == (6, 128, 3, 209)
+    assert (c.BOARD_SIZE, c.NUM_WALLS, c.NUM_PLIES_FOR_DRAW) == (9, 10, 116)
+    m = pg.GraphPolicyValueNetwork(6, 128, 3, 209)
+    keys = list(m.state_dict().keys())
+    assert sorted(keys) == sorted(pg.STATE_DICT_KEYS)
+    assert sum(p.numel() for p in m.parameters()) == 64082          # parameter count of the reference net
+    assert m.state_dict()["gcn_layers.0.lin.weight"].shape == (128, 6)
+    assert float(m.state_dict()["gcn_layers.1.bias"].abs().sum()) == 0.0
+
+
+def test_weight_packing_layout():
+    """aqg_gcn_pack_weights_host is host code: check the kernel layout (transposes, padding, fragment order)."""
+    from alphaquoridorgnn_amd import _lib
+    from oracle import gnn as og
+    lib = _lib.load()
+    p = og.init_params(5)
+    host = [np.ascontiguousarray(p[k], dtype=np.float32) for k in og.KEYS]
+    arr = (ctypes.c_void_p * 14)(*[h.ctypes.data_as(ctypes.c_void_p) for h in host])
+    n = lib.aqg_gcn_packed_floats(9)
+    out = np.zeros(n, dtype=np.float32)
+    assert lib.aqg_gcn_pack_weights_host(9, arr, out.ctypes.data_as(ctypes.c_void_p)) == 0
+    W1 = out[:128 * 8].reshape(128, 8)
+    assert np.array_equal(W1[:, :6], p["gcn_layers.0.lin.weight"]) and not W1[:, 6:].any()
+    off = 128 * 8 + 128
+    W2T = out[off:off + 128 * 128].reshape(128, 128)
+    assert np.array_equal(W2T, p["gcn_layers.1.lin.weight"].T)
+    wf2 = out[n - 2 * 128 * 128:n - 128 * 128].reshape(4, 2, 8, 64, 4)     # [wave][ntile][s4][lane][i]
+    for (w, j, s4, lane, i) in [(0, 0, 0, 0, 0), (3, 1, 7, 63, 3), (2, 0, 5, 17, 2), (1, 1, 2, 40, 1)]:
+        c, q = lane & 15, lane >> 4
+        k = (q & 1) * 64 + (q >> 1) * 32 + 4 * s4 + i
+        assert wf2[w, j, s4, lane, i] == p["gcn_layers.1.lin.weight"][32 * w + 16 * j + c, k]
+
+
+_GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["AQG_REPO"])
+import torch, torch.distributed as dist
+from alphaquoridorgnn_amd.engine import gather_history
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["AQG_PORT"], rank=int(os.environ["RANK"]), world_size=2)
+r = dist.get_rank()
+n = 5 if r == 0 else 3                      # ragged: ranks hold different numbers of positions
+st = torch.full((n, 72), 10 + r, dtype=torch.uint8)
+vis = (torch.arange(n * 209).view(n, 209) % 199 + 1000 * r).to(torch.int16)
+z = torch.tensor([(-1) ** i for i in range(n)], dtype=torch.int8) * (1 if r == 0 else -1)
+s, v, zz = gather_history(st, vis, z)
+assert s.shape == (8, 72) and v.shape == (8, 209) and zz.shape == (8,)
+assert (s[:5] == 10).all() and (s[5:] == 11).all()
+assert torch.equal(v[:5], (torch.arange(5 * 209).view(5, 209) % 199).to(torch.int16))
+assert torch.equal(v[5:], (torch.arange(3 * 209).view(3, 209) % 199 + 1000).to(torch.int16))
+assert zz.tolist() == [1, -1, 1, -1, 1, -1, 1, -1]
+# empty shard on one rank
+s, v, zz = gather_history(st[:0] if r == 1 else st, vis[:0] if r == 1 else vis, z[:0] if r == 1 else z)
+assert s.shape[0] == 5
+dist.destroy_process_group()
+print("ok", r)
+'''
+
+
+def test_gather_history_world_size_2_gloo(tmp_path):
+    """the one exchange step per generation -- ragged all-gather of (s, pi, z) -- on 2 gloo ranks."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), AQG_REPO=REPO, AQG_PORT=port, MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "ok" in o
+
+
+def test_self_play_sharding_arithmetic():
+    """Games split over ranks: every game is played exactly once (self_play.py:81-84 loop, sharded)."""
+    for total in (50, 2048, 7):
+        for world in (1, 2, 3, 8):
+            mine = [total // world + (1 if r < total % world else 0) for r in range(world)]
+            assert sum(mine) == total and max(mine) - min(mine) <= 1
