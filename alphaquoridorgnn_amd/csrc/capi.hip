@@ -35,7 +35,7 @@ int aqg_abi_version(void) { return AQG_ABI_VERSION; }
 const char* aqg_last_error(void) { return g_err; }
 
 int aqg_set_option(const char* name, int value) {
-    if (name && !strcmp(name, "trunk_variant")) { if (value < 0 || value > 2) return fail("trunk_variant must be 0, 1 or 2"); g_trunk_variant = value; return 0; }
+    if (name && !strcmp(name, "trunk_variant")) { if (value < 0 || value > 4) return fail("trunk_variant must be 0..4"); g_trunk_variant = value; return 0; }
     if (name && !strcmp(name, "profile_trunk")) { g_profile_trunk = value ? 1 : 0; return 0; }
     return fail("unknown option", name ? name : "(null)");
 }

@@ -46,10 +46,27 @@ struct PackedLayout {
     // MFMA B-fragment order of W2^T / W3^T: [wave 4][ntile 2][s4 8][lane 64][4]  (see load_wfrag)
     static constexpr size_t WF2 = VB2 + 4;
     static constexpr size_t WF3 = WF2 + HID * HID;
-    static constexpr size_t TOTAL = WF3 + HID * HID;
+    // bf16 3-way split (hi, mid, lo) of W2^T / W3^T in 16x16x32 MFMA B-fragment order, stored as raw dwords:
+    // [plane 3][wave 4][ntile 2][kblock 4][lane 64][4 dwords = 8 bf16]   (see load_bfrag)
+    static constexpr size_t WB2 = WF3 + HID * HID;
+    static constexpr size_t WB3 = WB2 + 3 * HID * HID / 2;
+    static constexpr size_t TOTAL = WB3 + 3 * HID * HID / 2;
 };
 
 size_t packed_floats() { return PackedLayout::TOTAL; }
+
+// round-to-nearest-even f32 -> bf16 (host side of the split; the device uses v_cvt_pk_bf16_f32, also RNE)
+static inline uint16_t host_bf16_rn(float x) {
+    uint32_t u; memcpy(&u, &x, 4);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+    return (uint16_t)u;
+}
+static inline float host_bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline void host_split3(float x, uint16_t (&pl)[3]) {
+    pl[0] = host_bf16_rn(x); float r = x - host_bf16_to_f32(pl[0]);
+    pl[1] = host_bf16_rn(r); r = r - host_bf16_to_f32(pl[1]);
+    pl[2] = host_bf16_rn(r);
+}
 
 // tensors (host fp32), state_dict order: gcn0.w[H,F] gcn0.b gcn1.w[H,H] gcn1.b gcn2.w gcn2.b
 // pol0.w[H/2,H] pol0.b pol2.w[A,H/2] pol2.b val0.w[H/2,H] val0.b val2.w[1,H/2] val2.b
@@ -78,6 +95,24 @@ int pack_weights_host(int N, const float* const* t, float* out) {
                         out[PackedLayout::WF2 + o] = t[2][n * HID + k];
                         out[PackedLayout::WF3 + o] = t[4][n * HID + k];
                     }
+    for (int L = 0; L < 2; ++L) {
+        const float* W = t[L == 0 ? 2 : 4];                       // [n][k]
+        uint32_t* dst = reinterpret_cast<uint32_t*>(out + (L == 0 ? PackedLayout::WB2 : PackedLayout::WB3));
+        for (int w = 0; w < 4; ++w)
+            for (int j = 0; j < 2; ++j)
+                for (int kb = 0; kb < 4; ++kb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int d = 0; d < 4; ++d) {
+                            const int c = lane & 15, q = lane >> 4, n = 32 * w + 16 * j + c;
+                            uint16_t a[3], b[3];
+                            host_split3(W[n * HID + 32 * kb + 8 * q + 2 * d], a);
+                            host_split3(W[n * HID + 32 * kb + 8 * q + 2 * d + 1], b);
+                            for (int pl = 0; pl < 3; ++pl) {
+                                const size_t o = (((((size_t)pl * 4 + w) * 2 + j) * 4 + kb) * 64 + lane) * 4 + d;
+                                dst[o] = (uint32_t)a[pl] | ((uint32_t)b[pl] << 16);
+                            }
+                        }
+    }
     for (int u = 0; u < HID / 2; ++u)
         for (int k = 0; k < HID; ++k) {
             out[PackedLayout::HW1T + k * HID + u] = t[6][u * HID + k];
@@ -457,6 +492,360 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_kernel(const
 #endif
 }
 
+// =============================================================================================
+// bf16-split trunk ("bf16xN"): the same network with the two 128x128 contractions on the bf16 matrix pipe.
+// Every f32 operand x is split into bf16 planes  x = hi + mid + lo  (each RNE of the running remainder), and
+//   a*b ~= hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi           (NT = 6: all terms down to 2^-24 |ab|)
+//   a*b ~= hi*hi + hi*lo' + lo'*hi                                     (NT = 3: two planes, ~2^-16 |ab|)
+// accumulated in f32 by v_mfma_f32_16x16x32_bf16 (16 cycles per 16x16x32 tile: 16x the f32-input MFMA rate, so
+// NT = 6 costs 6/16 of the exact-f32 MFMA time).  NT = 6 is fp32-equivalent for this network (logits within
+// 1e-8 of the exact-f32 path offline); both stay inside the stated 1e-5 / 1e-4 tolerance against the fp64 oracle.
+// The image lives in LDS as bf16 planes [plane][81][136]; the split is done ONCE per element in the stripe
+// epilogue (non-redundant), the MFMA phase reads ready-made fragments with ds_read_b128.
+// =============================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PROW = 272;                    // plane row stride in bytes: 128 bf16 + 16 B pad (17 slots of 16 B: odd)
+constexpr int PPLANE = 81 * PROW + 48;       // plane stride (22,080 B): == 4 (mod 16) slots -> conflict-free stripe reads
+
+template <int NPL>
+struct alignas(16) TrunkSmemB {
+    alignas(16) unsigned char P[NPL][PPLANE];   // bf16 planes of the activation image; a wave's stripe bytes of
+                                                // planes 0/1 double as its parked f32 XW stripe
+    alignas(16) float X0[81 * FPAD];
+    alignas(16) float AX[81 * FPAD];
+    alignas(16) float coef[96][8];
+    int obits[96];
+};
+
+__device__ __forceinline__ unsigned int pack_bf16x2(__bf16 a, __bf16 b) {
+    return (unsigned int)__builtin_bit_cast(unsigned short, a) | ((unsigned int)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+// split 4 f32 values into NPL bf16 planes and store them as 8 bytes per plane at byte offset `off` of each plane
+template <int NPL, typename SM>
+__device__ __forceinline__ void store_split4(SM& sm, int off, const f32x4 v) {
+    __bf16 h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (__bf16)v[e];
+        const float r1 = v[e] - (float)h[e];
+        m[e] = (__bf16)r1;
+        if (NPL == 3) l[e] = (__bf16)(r1 - (float)m[e]);
+    }
+    *reinterpret_cast<u32x2*>(&sm.P[0][off]) = (u32x2){pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3])};
+    *reinterpret_cast<u32x2*>(&sm.P[1][off]) = (u32x2){pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3])};
+    if (NPL == 3) *reinterpret_cast<u32x2*>(&sm.P[2][off]) = (u32x2){pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3])};
+}
+
+// B fragments: Bf[pl][j][kb] = 8 bf16 of plane pl: W[k = 32*kb + 8*q + 0..7][n = 32*wave + 16*j + c]
+template <int NPL>
+__device__ __forceinline__ void load_bfrag(u32x4 (&Bf)[NPL][2][4], const float* __restrict__ WB, int wave, int lane) {
+    const u32x4* base = reinterpret_cast<const u32x4*>(WB) + (size_t)__builtin_amdgcn_readfirstlane(wave) * (2 * 4 * 64) + lane;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) Bf[pl][j][kb] = base[(size_t)pl * (4 * 2 * 4 * 64) + (j * 4 + kb) * 64];
+}
+
+// MFMA phase: six 16-row tiles (rows >= 81 of the last tile are clamped to row 80 and discarded) x four 32-deep
+// k blocks; per (tile, block) NPL ds_read_b128 feed 2*NT MFMAs, smallest terms first.
+template <int NPL, typename SM>
+__device__ __forceinline__ void stripe_matmul_bf16(const SM& sm, const u32x4 (&Bf)[NPL][2][4], int lane, f32x4 (&acc)[6][2]) {
+    const int c = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    u32x4 cur[NPL], nxt[NPL];
+    const int row5 = (80 + c) > 80 ? 80 : 80 + c;           // tile 5: rows 80 + c clamped to 80
+    auto frag_off = [&](int step) -> int {                  // step = m*4 + kb
+        const int m = step >> 2, kb = step & 3;
+        const int row = (m < 5) ? 16 * m + c : row5;
+        return row * PROW + 64 * kb + 16 * q;
+    };
+    {
+        const int o = frag_off(0);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) cur[pl] = *reinterpret_cast<const u32x4*>(&sm.P[pl][o]);
+    }
+#pragma unroll
+    for (int step = 0; step < 24; ++step) {
+        const int m = step >> 2, kb = step & 3;
+        if (step < 23) {
+            const int o = frag_off(step + 1);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) nxt[pl] = *reinterpret_cast<const u32x4*>(&sm.P[pl][o]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 a = acc[m][j];
+            if (NPL == 3) {
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[2]), __builtin_bit_cast(bf16x8, Bf[0][j][kb]), a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[0]), __builtin_bit_cast(bf16x8, Bf[NPL - 1][j][kb]), a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[1]), __builtin_bit_cast(bf16x8, Bf[1][j][kb]), a, 0, 0, 0);
+            }
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[1]), __builtin_bit_cast(bf16x8, Bf[0][j][kb]), a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[0]), __builtin_bit_cast(bf16x8, Bf[1][j][kb]), a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[0]), __builtin_bit_cast(bf16x8, Bf[0][j][kb]), a, 0, 0, 0);
+            acc[m][j] = a;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (step < 23) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) cur[pl] = nxt[pl];
+        }
+    }
+}
+
+// stripe epilogue on the bf16 image: park XW (f32) in this wave's bytes of planes 0/1, gather + bias + ReLU,
+// then write the result back as split planes (or mean-pool when LAST).
+template <int NPL, bool LAST, typename SM>
+__device__ __forceinline__ void stripe_gather_bf16(SM& sm, const f32x4 (&acc)[6][2], const float* __restrict__ bias_g,
+                                                   int wave, int lane, float* __restrict__ pooled_out) {
+    {
+        const int c = lane & 15, q = lane >> 4;
+        const int o = (4 * q) * PROW + 64 * wave + 4 * c;
+#pragma unroll
+        for (int m = 0; m < 5; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<float*>(&sm.P[0][o + (16 * m + i) * PROW]) = acc[m][0][i];
+                *reinterpret_cast<float*>(&sm.P[1][o + (16 * m + i) * PROW]) = acc[m][1][i];
+            }
+        if (q == 0) {
+            *reinterpret_cast<float*>(&sm.P[0][80 * PROW + 64 * wave + 4 * c]) = acc[5][0][0];
+            *reinterpret_cast<float*>(&sm.P[1][80 * PROW + 64 * wave + 4 * c]) = acc[5][1][0];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int cg = lane & 7, rs = lane >> 3;
+    const int colb = 32 * wave + 4 * cg;
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_g + colb);
+    f32x4 out[STRIPE_ITERS];
+    const unsigned char* pbase = &sm.P[cg >> 2][0] + 64 * wave + 16 * (cg & 3);   // parked f32 x4 of columns colb..colb+3
+    const unsigned char* p1 = pbase + rs * 8 * PROW;
+    const unsigned char* p2 = pbase + (64 + rs) * PROW;
+    const float* k1 = &sm.coef[8 * rs][0];
+    const float* k2 = &sm.coef[64 + rs][0];
+    const int offU1 = rs == 0 ? 0 : -9 * PROW;
+#pragma unroll
+    for (int it = 0; it < STRIPE_ITERS; ++it) {
+        const unsigned char *ps, *pu, *pd, *pl, *pr;
+        const float* pk;
+        if (it < 8) {
+            ps = p1 + it * PROW; pk = k1 + it * 8;
+            pu = ps + offU1; pd = ps + 9 * PROW; pr = ps + PROW;
+            pl = (it == 0) ? (rs == 0 ? ps : ps - PROW) : ps - PROW;
+        } else if (it == 8) {
+            ps = p2; pk = k2; pu = ps - 9 * PROW; pd = ps + 9 * PROW; pl = ps - PROW; pr = ps + PROW;
+        } else if (it == 9) {
+            ps = p2 + 8 * PROW; pk = k2 + 64; pu = ps - 9 * PROW; pd = ps; pl = ps - PROW; pr = ps + PROW;
+        } else {
+            ps = pbase + 80 * PROW; pk = &sm.coef[80][0]; pu = ps - 9 * PROW; pd = ps; pl = ps - PROW; pr = ps;
+        }
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(pk);
+        const float kr = pk[4];
+        const f32x4 hs = *reinterpret_cast<const f32x4*>(ps);
+        const f32x4 hu = *reinterpret_cast<const f32x4*>(pu);
+        const f32x4 hd = *reinterpret_cast<const f32x4*>(pd);
+        const f32x4 hl = *reinterpret_cast<const f32x4*>(pl);
+        const f32x4 hr = *reinterpret_cast<const f32x4*>(pr);
+        f32x4 v = bias + k4[0] * hs + k4[1] * hu + k4[2] * hd + k4[3] * hl + kr * hr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        out[it] = v;
+        if (it & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!LAST) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < STRIPE_ITERS; ++it) {
+            const int r = stripe_row(it, rs);
+            if (r < 81) store_split4<NPL>(sm, r * PROW + 2 * colb, out[it]);
+        }
+    } else {
+        f32x4 sum = out[0];
+#pragma unroll
+        for (int it = 1; it < STRIPE_ITERS - 1; ++it) sum += out[it];
+        if (rs == 0) sum += out[STRIPE_ITERS - 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = sum[e];
+            x += __shfl_xor(x, 8); x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+            sum[e] = x * (1.0f / 81.0f);
+        }
+        if (rs == 0) *reinterpret_cast<f32x4*>(pooled_out + colb) = sum;
+    }
+}
+
+template <int NT, int WGS_PER_CU>
+__global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_bf16_kernel(const void* __restrict__ states, int fmt, int B,
+                                                                                 const float* __restrict__ pk,
+                                                                                 float* __restrict__ pooled,
+                                                                                 const uint8_t* __restrict__ active) {
+    constexpr int N = 9, V = 81, S = 8;
+    constexpr int NPL = (NT == 6) ? 3 : 2;
+    __shared__ TrunkSmemB<NPL> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const int ndw = fmt == 0 ? 18 : 6;
+    auto fetch_raw = [&](uint32_t (&raw)[18], int bb) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(states) + (size_t)bb * ndw;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) raw[i] = (i < ndw) ? src[i] : 0u;
+    };
+    auto unpack_raw = [&](const uint32_t (&raw)[18]) -> QState {
+        QState s;
+        if (fmt == 0) {
+            uint64_t h = 0, v = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                h |= (uint64_t)gather_bit0_x4(raw[1 + i]) << (4 * i);
+                v |= (uint64_t)gather_bit0_x4(raw[1 + i] >> 1) << (4 * i);
+            }
+            s.hw = h; s.vw = v;
+            s.ppos = (uint8_t)(raw[0] & 0xff); s.pwl = (uint8_t)((raw[0] >> 8) & 0xff);
+            s.epos = (uint8_t)((raw[0] >> 16) & 0xff); s.ewl = (uint8_t)(raw[0] >> 24);
+            s.plies = (uint16_t)(raw[17] & 0xffff);
+        } else {
+            s.hw = (uint64_t)raw[0] | ((uint64_t)raw[1] << 32);
+            s.vw = (uint64_t)raw[2] | ((uint64_t)raw[3] << 32);
+            s.ppos = (uint8_t)(raw[4] & 0xff); s.pwl = (uint8_t)((raw[4] >> 8) & 0xff);
+            s.epos = (uint8_t)((raw[4] >> 16) & 0xff); s.ewl = (uint8_t)(raw[4] >> 24);
+            s.plies = (uint16_t)(raw[5] & 0xffff);
+        }
+        s.pad = 0;
+        return s;
+    };
+    int b = blockIdx.x;
+    while (b < B && active && !active[b]) b += gridDim.x;
+    uint32_t raw[18];
+    if (b < B && tid < V) fetch_raw(raw, b);
+    u32x4 Bf[NPL][2][4];
+
+    AQG_STAMP_DECL
+    while (b < B) {
+        AQG_STAMP_AT(7)
+        // ---- setup step 1: node features + this tile's open-edge bits
+        if (tid < V) {
+            const QState s = unpack_raw(raw);
+            const int t = tid, x = t / N, y = t % N;
+            sm.obits[t] = tile_open_bits<N>(s.hw, s.vw, t);
+            const bool slot_ok = (x < S) && (y < S);
+            const int slot = x * S + y;
+            f32x4 xa, xb;
+            xa[0] = (t == s.ppos) ? 1.f : 0.f;
+            xa[1] = (float)s.pwl;
+            xa[2] = (t == s.epos) ? 1.f : 0.f;
+            xa[3] = (float)s.ewl;
+            xb[0] = (slot_ok && ((s.hw >> slot) & 1)) ? 1.f : 0.f;
+            xb[1] = (slot_ok && ((s.vw >> slot) & 1)) ? 1.f : 0.f;
+            xb[2] = 0.f; xb[3] = 0.f;
+            *reinterpret_cast<f32x4*>(sm.X0 + t * FPAD) = xa;
+            *reinterpret_cast<f32x4*>(sm.X0 + t * FPAD + 4) = xb;
+        }
+        int bn = b + gridDim.x;
+        while (bn < B && active && !active[bn]) bn += gridDim.x;
+        if (bn < B && tid < V) fetch_raw(raw, bn);
+        load_bfrag<NPL>(Bf, pk + PackedLayout::WB2, wave, lane);            // lands under layer 1
+        __syncthreads();
+        AQG_STAMP_AT(0)
+        // ---- setup step 2 + layer 1a
+        if (tid < V) {
+            const int t = tid;
+            const int ob = sm.obits[t];
+            const int tu = t >= 9 ? t - 9 : t, td = t < 72 ? t + 9 : t, tl = t > 0 ? t - 1 : t, tr = t < 80 ? t + 1 : t;
+            const float di = dinv_of_bits(ob);
+            f32x4 k4;
+            k4[0] = di * di;
+            k4[1] = (ob & 1) ? di * dinv_of_bits(sm.obits[tu]) : 0.f;
+            k4[2] = (ob & 2) ? di * dinv_of_bits(sm.obits[td]) : 0.f;
+            k4[3] = (ob & 4) ? di * dinv_of_bits(sm.obits[tl]) : 0.f;
+            const float kr = (ob & 8) ? di * dinv_of_bits(sm.obits[tr]) : 0.f;
+            *reinterpret_cast<f32x4*>(&sm.coef[t][0]) = k4;
+            sm.coef[t][4] = kr;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = k4[0] * *reinterpret_cast<const f32x4*>(sm.X0 + t * FPAD + 4 * h) +
+                                k4[1] * *reinterpret_cast<const f32x4*>(sm.X0 + tu * FPAD + 4 * h) +
+                                k4[2] * *reinterpret_cast<const f32x4*>(sm.X0 + td * FPAD + 4 * h) +
+                                k4[3] * *reinterpret_cast<const f32x4*>(sm.X0 + tl * FPAD + 4 * h) +
+                                kr * *reinterpret_cast<const f32x4*>(sm.X0 + tr * FPAD + 4 * h);
+                *reinterpret_cast<f32x4*>(sm.AX + t * FPAD + 4 * h) = v;
+            }
+        }
+        __syncthreads();
+        AQG_STAMP_AT(1)
+        // ---- layer 1b (f32 VALU, K = 6) -> split planes
+        {
+            const int cg = lane & 7, rs = lane >> 3;
+            const int colb = 32 * wave + 4 * cg;
+            float w1[4][6];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(pk + PackedLayout::W1 + (colb + e) * FPAD);
+                const float2 hi = *reinterpret_cast<const float2*>(pk + PackedLayout::W1 + (colb + e) * FPAD + 4);
+                w1[e][0] = lo[0]; w1[e][1] = lo[1]; w1[e][2] = lo[2]; w1[e][3] = lo[3]; w1[e][4] = hi.x; w1[e][5] = hi.y;
+            }
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(pk + PackedLayout::B1 + colb);
+#pragma unroll
+            for (int it = 0; it < STRIPE_ITERS; ++it) {
+                const int r = stripe_row(it, rs);
+                if (r < V) {
+                    const f32x4 xa = *reinterpret_cast<const f32x4*>(sm.AX + r * FPAD);
+                    const float2 xb = *reinterpret_cast<const float2*>(sm.AX + r * FPAD + 4);
+                    f32x4 v = b1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = v[e];
+                        a = fmaf(xa[0], w1[e][0], a); a = fmaf(xa[1], w1[e][1], a); a = fmaf(xa[2], w1[e][2], a);
+                        a = fmaf(xa[3], w1[e][3], a); a = fmaf(xb.x, w1[e][4], a); a = fmaf(xb.y, w1[e][5], a);
+                        v[e] = fmaxf(a, 0.f);
+                    }
+                    store_split4<NPL>(sm, r * PROW + 2 * colb, v);
+                }
+                if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        AQG_STAMP_AT(2)
+        // ---- layer 2
+        f32x4 acc[6][2];
+        stripe_matmul_bf16<NPL>(sm, Bf, lane, acc);
+        load_bfrag<NPL>(Bf, pk + PackedLayout::WB3, wave, lane);            // lands under the layer-2 epilogue
+        __syncthreads();
+        AQG_STAMP_AT(3)
+        stripe_gather_bf16<NPL, false>(sm, acc, pk + PackedLayout::B2, wave, lane, nullptr);
+        __syncthreads();
+        AQG_STAMP_AT(4)
+        // ---- layer 3 + mean pool
+        stripe_matmul_bf16<NPL>(sm, Bf, lane, acc);
+        __syncthreads();
+        AQG_STAMP_AT(5)
+        stripe_gather_bf16<NPL, true>(sm, acc, pk + PackedLayout::B3, wave, lane, pooled + (size_t)b * HID);
+        __syncthreads();
+        AQG_STAMP_AT(6)
+#ifdef AQG_STAMP
+        ++st_n;
+#endif
+        b = bn;
+    }
+#ifdef AQG_STAMP
+    if (blockIdx.x == 0 && tid == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(pooled + (size_t)B * HID);
+        for (int i = 0; i < 8; ++i) o[i] = st_sum[i];
+        o[8] = (unsigned long long)st_n;
+    }
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // heads: 16 boards per workgroup
 // ---------------------------------------------------------------------------------------------
@@ -570,7 +959,11 @@ __global__ __launch_bounds__(256) void gcn_heads_kernel(const float* __restrict_
     }
 }
 
-int g_trunk_variant = 1;  // set by aqg_set_option("trunk_variant", v)
+// Trunk variants (aqg_set_option("trunk_variant", v)):
+//   0 exact f32 MFMA, weights resident, 1 workgroup/CU      1 exact f32 MFMA, 2 workgroups/CU
+//   2 exact f32 MFMA, 3 workgroups/CU (spills; kept for A/B) 3 bf16x6 split MFMA (fp32-equivalent), 2/CU  [default]
+//   4 bf16x3 split MFMA (~2^-16 relative per product; still inside the stated tolerance), 2/CU
+int g_trunk_variant = 3;
 
 // Optional launch profiling of the dominant kernel (aqg_set_option("profile_trunk", 1)): a HIP event pair is
 // recorded around every trunk launch on the launch stream; aqg_profile_collect() reads them back.
@@ -624,9 +1017,15 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     } else if (g_trunk_variant == 1) {
         int grid = B < 512 ? B : 512;
         hipLaunchKernelGGL((gcn_trunk_boards_kernel<false, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
-    } else {
+    } else if (g_trunk_variant == 2) {
         int grid = B < 768 ? B : 768;
         hipLaunchKernelGGL((gcn_trunk_boards_kernel<false, 3>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
+    } else if (g_trunk_variant == 3) {
+        int grid = B < 512 ? B : 512;
+        hipLaunchKernelGGL((gcn_trunk_boards_bf16_kernel<6, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
+    } else {
+        int grid = B < 512 ? B : 512;
+        hipLaunchKernelGGL((gcn_trunk_boards_bf16_kernel<3, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
     }
     if (g_profile_trunk) hipEventRecord(prof_event(), st);
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;

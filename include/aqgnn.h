@@ -33,7 +33,8 @@ extern "C" {
 
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
-/* tuning knobs: "trunk_variant" 0 = weights resident in registers, 1 workgroup/CU; 1 = per-layer re-fetch, 2/CU */
+/* tuning knobs: "trunk_variant" 0/1/2 = exact f32-input MFMA with 1/2/3 workgroups per CU, 3 = bf16x6 split MFMA
+ * (fp32-equivalent products, default), 4 = bf16x3 split MFMA; "profile_trunk" 0/1 = event pairs around trunk launches */
 int aqg_set_option(const char* name, int value);
 /* Measurement aid (bench.py): with option "profile_trunk" = 1 a HIP event pair is recorded around every launch of the
  * dominant kernel (the GCN trunk) on its launch stream.  This call waits for the last recorded event, accumulates
@@ -77,7 +78,8 @@ int aqg_gcn_pack_weights_host(int board_size, const float* const* tensors_host, 
 
 /* GraphPolicyValueNetwork.forward  pv_network_gnn.py:53-64 on B boards given as state72 records: node
  * features = pv_network_cnn.py:88-114 read as [V,6]; graph = wall-cut 4-neighbour grid;
- * 3 x (GCNConv + ReLU) -> global_mean_pool -> heads.  fp32 throughout (f32-input MFMA for the contractions).
+ * 3 x (GCNConv + ReLU) -> global_mean_pool -> heads.  f32 data and accumulation throughout; the two 128x128
+ * contractions run on the matrix cores either as exact f32-input MFMA or as a 6-term bf16 split (default, same tolerance).
  *   pooled    [B,128]  workspace/out: mean-pooled trunk features
  *   logits    [B,A]    pre-softmax policy (may be NULL)
  *   policy    [B,A]    Softmax output == module output (may be NULL)

@@ -111,7 +111,7 @@ def test_legal_actions_large_batch_properties(dev):
 
 
 # ------------------------------------------------------------------ K1/K2 GNN forward
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4])
 def test_gnn_forward_boards_vs_fp64_oracle(dev, variant):
     from alphaquoridorgnn_amd import _lib
     from oracle import gnn as og
@@ -133,13 +133,16 @@ def test_gnn_forward_boards_vs_fp64_oracle(dev, variant):
     for B in (1, 3, 17):
         p2, v2 = model.forward_states(torch.from_numpy(recs[:B]).to(dev))
         assert torch.equal(p2, policy[:B]) and torch.equal(v2, value[:B])
-    _lib.set_option("trunk_variant", 1)
+    _lib.set_option("trunk_variant", 3)
 
 
-def test_gnn_forward_scaled_weights(dev):
+@pytest.mark.parametrize("variant", [1, 3])
+def test_gnn_forward_scaled_weights(dev, variant):
     """Weights scaled up so activations are O(10): relative tolerance still holds (catches layout slips that
     small random weights could hide)."""
+    from alphaquoridorgnn_amd import _lib
     from oracle import gnn as og
+    _lib.set_option("trunk_variant", variant)
     model, params = _model(3)
     big = {k: (v * (3.0 if "gcn" in k and "weight" in k else 1.0)).astype(np.float32) for k, v in params.items()}
     big["gcn_layers.1.bias"] = np.linspace(-0.5, 0.5, 128).astype(np.float32)
@@ -151,6 +154,7 @@ def test_gnn_forward_scaled_weights(dev):
     _, _, logits, vpre = model.forward_states(torch.from_numpy(recs).to(dev), want_logits=True)
     np.testing.assert_allclose(logits.cpu().numpy(), ref["logits"], atol=2e-4, rtol=2e-4)
     np.testing.assert_allclose(vpre.cpu().numpy(), ref["value_pre"], atol=2e-4, rtol=2e-4)
+    _lib.set_option("trunk_variant", 3)
 
 
 def test_gnn_forward_generic_graph(dev):

@@ -84,13 +84,13 @@ def main():
                 _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy),
                                                       None, _lib.ptr(value), _lib.stream_ptr(dev)), "full")
             for rnd in range(2):
-                for v in (0, 1, 2):
+                for v in (1, 3, 4):
                     _lib.set_option("trunk_variant", v)
                     t = time_ms(trunk, args.iters)
                     f = time_ms(full, args.iters)
                     out[f"gnn_B{B}_v{v}_r{rnd}"] = dict(trunk_ms=round(t, 4), full_ms=round(f, 4), boards_per_s=round(B / f * 1e3),
                                                         mfma_frac=round(B / t * 1e3 * 5432832 / 157.3e12, 4))
-            _lib.set_option("trunk_variant", 1)
+            _lib.set_option("trunk_variant", 3)
     if "legal" in args.what:
         for B in (4096, 65536):
             st = synth_states(B, seed=1)

@@ -18,7 +18,7 @@ model = GNNNetwork().to(dev).eval(); pk = model.packed_weights(dev)
 B = 65536
 st = synth_states(B)
 names = ["setup", "L1a gather6", "L1b 6->128", "L2 mfma", "L2 stripe gather", "L3 mfma", "L3 gather+pool", "loop top"]
-for v in (0, 1):
+for v in (1, 3, 4):
     _lib.set_option("trunk_variant", v)
     pooled = torch.zeros((B + 1, 128), device=dev)
     for _ in range(3):
