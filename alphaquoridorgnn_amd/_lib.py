@@ -37,6 +37,7 @@ SIGNATURES = {
     "aqg_abi_version": (_c.c_int, []),
     "aqg_last_error": (_c.c_char_p, []),
     "aqg_set_option": (_c.c_int, [_c.c_char_p, _c.c_int]),
+    "aqg_debug_poison_lds": (_c.c_int, [_vp]),
     "aqg_profile_collect": (_c.c_int, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_longlong), _c.POINTER(_c.c_longlong), _c.c_int]),
     "aqg_legal_actions": (_c.c_int, [_c.c_int, _vp, _c.c_int, _vp, _vp, _vp, _vp]),
     "aqg_state_next": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_int, _vp, _vp]),
@@ -112,3 +113,8 @@ def profile_collect(reset=False):
     ms, n, b = _c.c_double(0), _c.c_longlong(0), _c.c_longlong(0)
     check(load().aqg_profile_collect(_c.byref(ms), _c.byref(n), _c.byref(b), 1 if reset else 0), "aqg_profile_collect")
     return ms.value, n.value, b.value
+
+
+def poison_lds(device=None):
+    """Fill every CU's LDS with NaN patterns (tests: makes LDS read-before-write deterministic)."""
+    check(load().aqg_debug_poison_lds(stream_ptr(device)), "aqg_debug_poison_lds")

@@ -7,6 +7,7 @@ thread_local char g_err[512] = "";
 extern int g_trunk_variant;
 extern int g_profile_trunk;
 int profile_collect(double* total_ms, long long* launches, long long* boards, int reset);
+int launch_poison_lds(hipStream_t st);
 
 size_t packed_floats();
 int pack_weights_host(int N, const float* const* t, float* out);
@@ -39,6 +40,8 @@ int aqg_set_option(const char* name, int value) {
     if (name && !strcmp(name, "profile_trunk")) { g_profile_trunk = value ? 1 : 0; return 0; }
     return fail("unknown option", name ? name : "(null)");
 }
+
+int aqg_debug_poison_lds(void* stream) { return launch_poison_lds((hipStream_t)stream); }
 
 int aqg_profile_collect(double* total_ms_host, long long* launches_host, long long* boards_host, int reset) {
     return profile_collect(total_ms_host, launches_host, boards_host, reset);

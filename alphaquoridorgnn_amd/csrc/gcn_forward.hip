@@ -264,7 +264,7 @@ __device__ __forceinline__ void stripe_gather(TrunkSmem& sm, const f32x4 (&acc)[
     const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_g + colb);
     f32x4 out[STRIPE_ITERS];
     // Row r's neighbours sit at fixed row offsets (-9, +9, -1, +1); off-board ones are clamped to r itself (their
-    // coefficient is 0).  With the schedule of stripe_row() every clamp is known at compile time except
+    // coefficient is 0 -- but the clamp is REQUIRED: 0 x NaN garbage is NaN, which the ReLU would silently turn into 0).  With the schedule of stripe_row() every clamp is known at compile time except
     // "up" in iterations 0..7 (only the rs == 0 lanes have r < 9), which is one per-lane offset.
     const float* p1 = sm.H + colb + rs * 8 * LD;          // iteration it < 8: row it + 8*rs
     const float* p2 = sm.H + colb + (64 + rs) * LD;       // iteration 8, 9: rows 64+rs, 72+rs
@@ -276,7 +276,8 @@ __device__ __forceinline__ void stripe_gather(TrunkSmem& sm, const f32x4 (&acc)[
         const float *ps, *pu, *pd, *pl, *pr, *pk;
         if (it < 8) {
             ps = p1 + it * LD; pk = k1 + it * 8;
-            pu = ps + offU1; pd = ps + 9 * LD; pr = ps + LD;
+            pu = (it == 0) ? (rs <= 1 ? ps : ps - 9 * LD) : ps + offU1;   // rows it + 8*rs < 9: rs == 0, and row 8 (it 0, rs 1)
+            pd = ps + 9 * LD; pr = ps + LD;
             pl = (it == 0) ? (rs == 0 ? ps : ps - LD) : ps - LD;
         } else if (it == 8) {
             ps = p2; pk = k2; pu = ps - 9 * LD; pd = ps + 9 * LD; pl = ps - LD; pr = ps + LD;
@@ -641,7 +642,8 @@ __device__ __forceinline__ void stripe_gather_bf16(SM& sm, const f32x4 (&acc)[6]
         const float* pk;
         if (it < 8) {
             ps = p1 + it * PROW; pk = k1 + it * 8;
-            pu = ps + offU1; pd = ps + 9 * PROW; pr = ps + PROW;
+            pu = (it == 0) ? (rs <= 1 ? ps : ps - 9 * PROW) : ps + offU1;   // rows it + 8*rs < 9: rs == 0, and row 8 (it 0, rs 1)
+            pd = ps + 9 * PROW; pr = ps + PROW;
             pl = (it == 0) ? (rs == 0 ? ps : ps - PROW) : ps - PROW;
         } else if (it == 8) {
             ps = p2; pk = k2; pu = ps - 9 * PROW; pd = ps + 9 * PROW; pl = ps - PROW; pr = ps + PROW;
@@ -964,6 +966,19 @@ __global__ __launch_bounds__(256) void gcn_heads_kernel(const float* __restrict_
 //   2 exact f32 MFMA, 3 workgroups/CU (spills; kept for A/B) 3 bf16x6 split MFMA (fp32-equivalent), 2/CU  [default]
 //   4 bf16x3 split MFMA (~2^-16 relative per product; still inside the stated tolerance), 2/CU
 int g_trunk_variant = 3;
+
+// Diagnostic: fill every CU's LDS with NaN bit patterns so that any read-before-write in a later kernel shows up
+// deterministically (used by the parity tests; LDS contents are otherwise whatever the previous kernel left).
+__global__ __launch_bounds__(256, 2) void poison_lds_kernel(unsigned int* sink) {
+    __shared__ unsigned int buf[20000];     // 80,000 B: two workgroups per CU cover 160 KB
+    for (int i = threadIdx.x; i < 20000; i += 256) buf[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (sink && buf[(threadIdx.x * 77) % 20000] == 0x12345678u) sink[0] = 1;   // keep the stores alive
+}
+int launch_poison_lds(hipStream_t st) {
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(256), 0, st, (unsigned int*)nullptr);
+    return check_launch("poison_lds_kernel");
+}
 
 // Optional launch profiling of the dominant kernel (aqg_set_option("profile_trunk", 1)): a HIP event pair is
 // recorded around every trunk launch on the launch stream; aqg_profile_collect() reads them back.

@@ -7,6 +7,7 @@
 // popcounts, so no atomics and no sorting.  Integer/bit work only: the bound is VALU issue + divergence,
 // not HBM (100 algorithmic bytes per state).
 #include "aqg_common.hpp"
+#include "legal_wave.hpp"
 
 namespace aqg {
 
@@ -15,48 +16,14 @@ __global__ __launch_bounds__(256) void legal_actions_kernel(const void* __restri
                                                             uint8_t* __restrict__ mask, uint8_t* __restrict__ order,
                                                             int32_t* __restrict__ count,
                                                             const uint8_t* __restrict__ active) {
-    constexpr int V = Geo<N>::V, NW = Geo<N>::NW, A = Geo<N>::A;
+    constexpr int A = Geo<N>::A;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;
     if (active && !active[b]) return;
     const QState s = load_state(states, fmt, b);
-    const Open base = make_open<N>(s.hw, s.vw);
-
-    bool legH = false, legV = false;
-    if (s.pwl > 0 && lane < NW) {
-        uint64_t hp, vp;
-        placeable_masks<N>(s.hw, s.vw, hp, vp);
-        if ((hp >> lane) & 1) legH = wall_keeps_paths<N>(s, base, 1, lane);
-        if ((vp >> lane) & 1) legV = wall_keeps_paths<N>(s, base, 2, lane);
-    }
-    const uint64_t mH = __ballot(legH), mV = __ballot(legV);
-
-    uint8_t pawn[8];
-    const int npawn = legal_pos_list<N>(base, s.ppos, V - 1 - s.epos, pawn);
-    const int total = npawn + __popcll(mH) + __popcll(mV);
-
-    if (mask) {
-        uint8_t* m = mask + (size_t)b * A;
-        for (int a = lane; a < A; a += 64) {
-            bool on;
-            if (a < V) {
-                on = false;
-                for (int i = 0; i < npawn; ++i) on |= (pawn[i] == a);
-            } else if (a < V + NW) on = (mH >> (a - V)) & 1;
-            else on = (mV >> (a - V - NW)) & 1;
-            m[a] = on ? 1 : 0;
-        }
-    }
-    if (order) {
-        uint8_t* o = order + (size_t)b * MAX_LEGAL;
-        const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const int prefix = npawn + __popcll(mH & below) + __popcll(mV & below);
-        if (legH) o[prefix] = (uint8_t)(V + lane);
-        if (legV) o[prefix + (legH ? 1 : 0)] = (uint8_t)(V + NW + lane);
-        if (lane < npawn) o[lane] = pawn[lane];
-        for (int i = total + lane; i < MAX_LEGAL; i += 64) o[i] = 0xFF;
-    }
+    const int total = wave_legal_actions<N>(s, lane, mask ? mask + (size_t)b * A : nullptr,
+                                            order ? order + (size_t)b * MAX_LEGAL : nullptr);
     if (count && lane == 0) count[b] = total;
 }
 

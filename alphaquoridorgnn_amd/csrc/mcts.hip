@@ -10,10 +10,12 @@
 // so the PUCT arg-max is a strided wave reduction and "first maximum wins" is (max score, min index).
 // Child STATES are never stored: the descent re-applies next() from the root's 24-byte packed state, so
 // a node costs 21 bytes instead of the reference's full State copy.
-// One simulation = select kernel -> (legal_actions + GNN on the leaf batch) -> expand/backup kernel;
+// One simulation = fused step kernel (expand/backup of the previous leaf, select, legal actions of the new leaf)
+// -> GNN trunk -> GNN heads on the leaf batch;
 // every game has exactly one leaf in flight, so no virtual loss is needed and per-game semantics equal the
 // sequential reference.
 #include "aqg_common.hpp"
+#include "legal_wave.hpp"
 #include "../../include/aqgnn.h"
 
 // PUCT scores must be evaluated exactly as written (no fma contraction, IEEE divide/sqrt).
@@ -111,10 +113,7 @@ __global__ void engine_begin_move_kernel(aqg_engine e) {
 // select: descend by PUCT to a terminal node (back up at once) or to an unexpanded leaf (emit its state)
 // ------------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(256) void engine_select_kernel(aqg_engine e) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= e.num_games) return;
+__device__ __forceinline__ void game_select(const aqg_engine& e, int g, int lane) {
     if (!e.game_active[g]) { if (lane == 0) e.leaf_flag[g] = 0; return; }
     if (lane == 0) e.leaf_flag[g] = 0;
     const size_t nb = (size_t)g * e.node_cap;
@@ -190,10 +189,15 @@ __global__ __launch_bounds__(256) void engine_select_kernel(aqg_engine e) {
                 e.node_n[idx] += 1;
             }
         }
-    } else if (lane == 0) {
-        store_state(e.leaf_state, g, s);
-        e.path_len[g] = depth;
-        e.leaf_flag[g] = 1;
+    } else {
+        // unexpanded leaf: its legal actions are computed right here by the same wavefront (one lane per wall slot)
+        const int total = wave_legal_actions<N>(s, lane, nullptr, e.legal_order + (size_t)g * MAX_LEGAL);
+        if (lane == 0) {
+            store_state(e.leaf_state, g, s);
+            e.legal_count[g] = total;
+            e.path_len[g] = depth;
+            e.leaf_flag[g] = 1;
+        }
     }
 }
 
@@ -249,11 +253,9 @@ __global__ __launch_bounds__(256) void engine_fake_eval_kernel(aqg_engine e) {
 // expand + backup (pv_mcts.py:47-57, :60-66)
 // ------------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(256) void engine_expand_backup_kernel(aqg_engine e) {
+__device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, int lane) {
     constexpr int A = Geo<N>::A;
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= e.num_games || e.leaf_flag[g] != 1) return;
+    if (e.leaf_flag[g] != 1) return;
     const size_t nb = (size_t)g * e.node_cap;
     const int* path = e.path + (size_t)g * (e.sims + 2);
     const int depth = e.path_len[g];
@@ -299,6 +301,29 @@ __global__ __launch_bounds__(256) void engine_expand_backup_kernel(aqg_engine e)
     }
     backup_path(e, nb, path, depth, (double)e.value[g], lane);   // value.item() -> python float
     if (lane == 0) e.stat_leaf_evals[g] += 1;   // per-game slot: a shared counter would serialise 2048 atomics per step
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused simulation step, one wavefront per game:
+//   [expand + backup of the PREVIOUS simulation's leaf]  ->  [select the next leaf + its legal actions]
+// Both halves touch only this game's pools, and the wave that wrote the children is the wave that reads them, so
+// a workgroup-scope fence is all the ordering needed.  Per simulation the engine then launches
+// step -> GNN trunk -> GNN heads (3 kernels instead of select / legal / trunk / heads / expand).
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void engine_step_kernel(aqg_engine e, int do_expand, int do_select) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= e.num_games) return;
+    if (do_expand) game_expand_backup<N>(e, g, lane);
+    if (do_select) {
+        if (do_expand) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        game_select<N>(e, g, lane);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -413,9 +438,7 @@ static int run_sims(const aqg_engine& e, hipStream_t st) {
     const dim3 grid((e.num_games + 3) / 4), block(256);
     hipLaunchKernelGGL(engine_begin_move_kernel, dim3((e.num_games + 255) / 256), dim3(256), 0, st, e);
     for (int sim = 0; sim < e.sims; ++sim) {
-        hipLaunchKernelGGL(engine_select_kernel<N>, grid, block, 0, st, e);
-        if (int r = launch_legal_actions(N, e.leaf_state, 1, e.num_games, nullptr, e.legal_order, e.legal_count, e.leaf_flag, st))
-            return r;
+        hipLaunchKernelGGL(engine_step_kernel<N>, grid, block, 0, st, e, sim > 0 ? 1 : 0, 1);
         if (e.prior_mode == 0) {
             if (int r = launch_gcn_forward_boards(N, e.leaf_state, 1, e.num_games, e.packed_weights, e.pooled, nullptr, e.policy,
                                                   nullptr, e.value, e.leaf_flag, st))
@@ -423,8 +446,8 @@ static int run_sims(const aqg_engine& e, hipStream_t st) {
         } else {
             hipLaunchKernelGGL(engine_fake_eval_kernel<N>, grid, block, 0, st, e);
         }
-        hipLaunchKernelGGL(engine_expand_backup_kernel<N>, grid, block, 0, st, e);
     }
+    hipLaunchKernelGGL(engine_step_kernel<N>, grid, block, 0, st, e, 1, 0);   // expand + backup of the last simulation
     return check_launch("engine simulation kernels");
 }
 

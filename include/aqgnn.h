@@ -41,6 +41,9 @@ int aqg_set_option(const char* name, int value);
  * the elapsed times and returns the running totals (HOST pointers; `boards` = sum of launch batch sizes incl.
  * masked-out rows); reset != 0 clears the totals.  It is the only entry point that blocks the host. */
 int aqg_profile_collect(double* total_ms_host, long long* launches_host, long long* boards_host, int reset);
+/* Test aid: overwrite the LDS of every CU with NaN bit patterns (stream-ordered), so a kernel that reads LDS it
+ * has not written fails deterministically instead of depending on what the previous kernel left behind. */
+int aqg_debug_poison_lds(void* stream);
 
 /* ------------------------------------------------------------------ game rules (game_logic.py) */
 

@@ -121,8 +121,10 @@ def test_gnn_forward_boards_vs_fp64_oracle(dev, variant):
     sel = np.linspace(0, g["states"].shape[0] - 1, 300).astype(int)
     recs = g["states"][sel]
     ref = og.forward_states(params, recs)
+    _lib.poison_lds(dev)                 # NaN-fill LDS: any read-before-write inside the kernels becomes visible
     policy, value, logits, vpre = model.forward_states(torch.from_numpy(recs).to(dev), want_logits=True)
     logits, vpre = logits.cpu().numpy().astype(np.float64), vpre.cpu().numpy().astype(np.float64)
+    assert np.isfinite(logits).all() and np.isfinite(vpre).all()
     # stated tolerance (fp32 MFMA path): atol 1e-5, rtol 1e-4 on logits / pre-tanh value
     np.testing.assert_allclose(logits, ref["logits"], atol=1e-5, rtol=1e-4)
     np.testing.assert_allclose(vpre, ref["value_pre"], atol=1e-5, rtol=1e-4)
@@ -131,6 +133,7 @@ def test_gnn_forward_boards_vs_fp64_oracle(dev, variant):
     assert np.allclose(policy.sum(1).cpu().numpy(), 1.0, atol=1e-5)
     # ragged / tiny / odd batch sizes give the same rows
     for B in (1, 3, 17):
+        _lib.poison_lds(dev)
         p2, v2 = model.forward_states(torch.from_numpy(recs[:B]).to(dev))
         assert torch.equal(p2, policy[:B]) and torch.equal(v2, value[:B])
     _lib.set_option("trunk_variant", 3)
