@@ -511,14 +511,20 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int PROW = 272;                    // plane row stride in bytes: 128 bf16 + 16 B pad (17 slots of 16 B: odd)
 constexpr int PPLANE = 81 * PROW + 48;       // plane stride (22,080 B): == 4 (mod 16) slots -> conflict-free stripe reads
 
+// Row permutation for the small per-row tables (coef, AX): rows handled by one instruction are r = it + 8*rs, i.e.
+// 8 apart; with 32-byte rows that is a 256-byte stride = every lane group on the same banks (4-way conflicts).
+// Class-major order puts the rows of one iteration next to each other instead.
+__device__ __forceinline__ int prow(int r) { return (r & 7) * 11 + (r >> 3); }   // 0..87 for r in 0..80
+
 template <int NPL>
 struct alignas(16) TrunkSmemB {
     alignas(16) unsigned char P[NPL][PPLANE];   // bf16 planes of the activation image; a wave's stripe bytes of
                                                 // planes 0/1 double as its parked f32 XW stripe
     alignas(16) float X0[81 * FPAD];
-    alignas(16) float AX[81 * FPAD];
-    alignas(16) float coef[96][8];
+    alignas(16) float AX[88 * FPAD];            // indexed by prow(r)
+    alignas(16) float coef[88][8];              // indexed by prow(r)
     int obits[96];
+    unsigned int raw[20];                       // next board's record, staged by <= 18 lanes (1 VGPR instead of 18)
 };
 
 __device__ __forceinline__ unsigned int pack_bf16x2(__bf16 a, __bf16 b) {
@@ -608,7 +614,7 @@ __device__ __forceinline__ void stripe_matmul_bf16(const SM& sm, const u32x4 (&B
 // stripe epilogue on the bf16 image: park XW (f32) in this wave's bytes of planes 0/1, gather + bias + ReLU,
 // then write the result back as split planes (or mean-pool when LAST).
 template <int NPL, bool LAST, typename SM>
-__device__ __forceinline__ void stripe_gather_bf16(SM& sm, const f32x4 (&acc)[6][2], const float* __restrict__ bias_g,
+__device__ __forceinline__ void stripe_gather_bf16(SM& sm, const f32x4 (&acc)[6][2], const f32x4 bias,
                                                    int wave, int lane, float* __restrict__ pooled_out) {
     {
         const int c = lane & 15, q = lane >> 4;
@@ -628,29 +634,28 @@ __device__ __forceinline__ void stripe_gather_bf16(SM& sm, const f32x4 (&acc)[6]
     __builtin_amdgcn_wave_barrier();
     const int cg = lane & 7, rs = lane >> 3;
     const int colb = 32 * wave + 4 * cg;
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_g + colb);
     f32x4 out[STRIPE_ITERS];
     const unsigned char* pbase = &sm.P[cg >> 2][0] + 64 * wave + 16 * (cg & 3);   // parked f32 x4 of columns colb..colb+3
     const unsigned char* p1 = pbase + rs * 8 * PROW;
     const unsigned char* p2 = pbase + (64 + rs) * PROW;
-    const float* k1 = &sm.coef[8 * rs][0];
-    const float* k2 = &sm.coef[64 + rs][0];
+    const float* k1 = &sm.coef[rs][0];                  // iteration it < 8: prow(it + 8*rs) = it*11 + rs
+    const float* k2 = &sm.coef[rs * 11 + 8][0];         // iteration 8: prow(64 + rs) = rs*11 + 8; iteration 9: +1
     const int offU1 = rs == 0 ? 0 : -9 * PROW;
 #pragma unroll
     for (int it = 0; it < STRIPE_ITERS; ++it) {
         const unsigned char *ps, *pu, *pd, *pl, *pr;
         const float* pk;
         if (it < 8) {
-            ps = p1 + it * PROW; pk = k1 + it * 8;
+            ps = p1 + it * PROW; pk = k1 + it * 11 * 8;
             pu = (it == 0) ? (rs <= 1 ? ps : ps - 9 * PROW) : ps + offU1;   // rows it + 8*rs < 9: rs == 0, and row 8 (it 0, rs 1)
             pd = ps + 9 * PROW; pr = ps + PROW;
             pl = (it == 0) ? (rs == 0 ? ps : ps - PROW) : ps - PROW;
         } else if (it == 8) {
             ps = p2; pk = k2; pu = ps - 9 * PROW; pd = ps + 9 * PROW; pl = ps - PROW; pr = ps + PROW;
         } else if (it == 9) {
-            ps = p2 + 8 * PROW; pk = k2 + 64; pu = ps - 9 * PROW; pd = ps; pl = ps - PROW; pr = ps + PROW;
+            ps = p2 + 8 * PROW; pk = k2 + 8; pu = ps - 9 * PROW; pd = ps; pl = ps - PROW; pr = ps + PROW;
         } else {
-            ps = pbase + 80 * PROW; pk = &sm.coef[80][0]; pu = ps - 9 * PROW; pd = ps; pl = ps - PROW; pr = ps;
+            ps = pbase + 80 * PROW; pk = &sm.coef[prow(80)][0]; pu = ps - 9 * PROW; pd = ps; pl = ps - PROW; pr = ps;
         }
         const f32x4 k4 = *reinterpret_cast<const f32x4*>(pk);
         const float kr = pk[4];
@@ -695,50 +700,51 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_bf16_kernel(
     constexpr int N = 9, V = 81, S = 8;
     constexpr int NPL = (NT == 6) ? 3 : 2;
     __shared__ TrunkSmemB<NPL> sm;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: wave-derived offsets stay in SGPRs
 
     const int ndw = fmt == 0 ? 18 : 6;
-    auto fetch_raw = [&](uint32_t (&raw)[18], int bb) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(states) + (size_t)bb * ndw;
-#pragma unroll
-        for (int i = 0; i < 18; ++i) raw[i] = (i < ndw) ? src[i] : 0u;
-    };
-    auto unpack_raw = [&](const uint32_t (&raw)[18]) -> QState {
-        QState s;
-        if (fmt == 0) {
-            uint64_t h = 0, v = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                h |= (uint64_t)gather_bit0_x4(raw[1 + i]) << (4 * i);
-                v |= (uint64_t)gather_bit0_x4(raw[1 + i] >> 1) << (4 * i);
-            }
-            s.hw = h; s.vw = v;
-            s.ppos = (uint8_t)(raw[0] & 0xff); s.pwl = (uint8_t)((raw[0] >> 8) & 0xff);
-            s.epos = (uint8_t)((raw[0] >> 16) & 0xff); s.ewl = (uint8_t)(raw[0] >> 24);
-            s.plies = (uint16_t)(raw[17] & 0xffff);
-        } else {
-            s.hw = (uint64_t)raw[0] | ((uint64_t)raw[1] << 32);
-            s.vw = (uint64_t)raw[2] | ((uint64_t)raw[3] << 32);
-            s.ppos = (uint8_t)(raw[4] & 0xff); s.pwl = (uint8_t)((raw[4] >> 8) & 0xff);
-            s.epos = (uint8_t)((raw[4] >> 16) & 0xff); s.ewl = (uint8_t)(raw[4] >> 24);
-            s.plies = (uint16_t)(raw[5] & 0xffff);
-        }
-        s.pad = 0;
-        return s;
-    };
     int b = blockIdx.x;
     while (b < B && active && !active[b]) b += gridDim.x;
-    uint32_t raw[18];
-    if (b < B && tid < V) fetch_raw(raw, b);
+    if (b < B && tid < ndw) sm.raw[tid] = reinterpret_cast<const uint32_t*>(states)[(size_t)b * ndw + tid];
+    __syncthreads();
     u32x4 Bf[NPL][2][4];
 
     AQG_STAMP_DECL
     while (b < B) {
         AQG_STAMP_AT(7)
+        // Global loads are issued right AFTER a barrier, never just before one: __syncthreads() waits vmcnt(0), so a
+        // load issued ahead of it exposes its whole L2 latency, while one issued behind it lands under the next phase.
+        // vmcnt retires in order: a small load issued AFTER a prefetch can only be waited for by draining the whole
+        // prefetch, so the per-layer biases are fetched first and handed to the gathers by value.
+        const f32x4 bias2 = *reinterpret_cast<const f32x4*>(pk + PackedLayout::B2 + 32 * wave + 4 * (lane & 7));
+        const f32x4 bias3 = *reinterpret_cast<const f32x4*>(pk + PackedLayout::B3 + 32 * wave + 4 * (lane & 7));
+        load_bfrag<NPL>(Bf, pk + PackedLayout::WB2, wave, lane);            // lands under setup + layer 1
+        __builtin_amdgcn_sched_barrier(0);                                  // keep the loads at the phase start
         // ---- setup step 1: node features + this tile's open-edge bits
         if (tid < V) {
-            const QState s = unpack_raw(raw);
-            const int t = tid, x = t / N, y = t % N;
+            QState s;
+            if (fmt == 0) {
+                uint64_t h = 0, v = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t x = sm.raw[1 + i];
+                    h |= (uint64_t)gather_bit0_x4(x) << (4 * i);
+                    v |= (uint64_t)gather_bit0_x4(x >> 1) << (4 * i);
+                }
+                s.hw = h; s.vw = v;
+            } else {
+                s.hw = (uint64_t)sm.raw[0] | ((uint64_t)sm.raw[1] << 32);
+                s.vw = (uint64_t)sm.raw[2] | ((uint64_t)sm.raw[3] << 32);
+            }
+            const uint32_t hd = sm.raw[fmt == 0 ? 0 : 4];
+            s.ppos = (uint8_t)(hd & 0xff); s.pwl = (uint8_t)((hd >> 8) & 0xff);
+            s.epos = (uint8_t)((hd >> 16) & 0xff); s.ewl = (uint8_t)(hd >> 24);
+            s.plies = 0; s.pad = 0;
+            int t = tid;
+            asm volatile("" : "+v"(t));   // opaque per iteration: keeps hipcc from hoisting (and then spilling) the
+                                          // per-tile masks / addresses out of the board loop
+            const int x = t / N, y = t % N;
             sm.obits[t] = tile_open_bits<N>(s.hw, s.vw, t);
             const bool slot_ok = (x < S) && (y < S);
             const int slot = x * S + y;
@@ -755,13 +761,14 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_bf16_kernel(
         }
         int bn = b + gridDim.x;
         while (bn < B && active && !active[bn]) bn += gridDim.x;
-        if (bn < B && tid < V) fetch_raw(raw, bn);
-        load_bfrag<NPL>(Bf, pk + PackedLayout::WB2, wave, lane);            // lands under layer 1
         __syncthreads();
         AQG_STAMP_AT(0)
+        uint32_t rawreg = 0;                                                // next board's record: one dword per lane,
+        if (bn < B && tid < ndw) rawreg = reinterpret_cast<const uint32_t*>(states)[(size_t)bn * ndw + tid];   // parked in LDS below
         // ---- setup step 2 + layer 1a
         if (tid < V) {
-            const int t = tid;
+            int t = tid;
+            asm volatile("" : "+v"(t));
             const int ob = sm.obits[t];
             const int tu = t >= 9 ? t - 9 : t, td = t < 72 ? t + 9 : t, tl = t > 0 ? t - 1 : t, tr = t < 80 ? t + 1 : t;
             const float di = dinv_of_bits(ob);
@@ -771,8 +778,8 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_bf16_kernel(
             k4[2] = (ob & 2) ? di * dinv_of_bits(sm.obits[td]) : 0.f;
             k4[3] = (ob & 4) ? di * dinv_of_bits(sm.obits[tl]) : 0.f;
             const float kr = (ob & 8) ? di * dinv_of_bits(sm.obits[tr]) : 0.f;
-            *reinterpret_cast<f32x4*>(&sm.coef[t][0]) = k4;
-            sm.coef[t][4] = kr;
+            *reinterpret_cast<f32x4*>(&sm.coef[prow(t)][0]) = k4;
+            sm.coef[prow(t)][4] = kr;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f32x4 v = k4[0] * *reinterpret_cast<const f32x4*>(sm.X0 + t * FPAD + 4 * h) +
@@ -780,7 +787,7 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_bf16_kernel(
                                 k4[2] * *reinterpret_cast<const f32x4*>(sm.X0 + td * FPAD + 4 * h) +
                                 k4[3] * *reinterpret_cast<const f32x4*>(sm.X0 + tl * FPAD + 4 * h) +
                                 kr * *reinterpret_cast<const f32x4*>(sm.X0 + tr * FPAD + 4 * h);
-                *reinterpret_cast<f32x4*>(sm.AX + t * FPAD + 4 * h) = v;
+                *reinterpret_cast<f32x4*>(sm.AX + prow(t) * FPAD + 4 * h) = v;
             }
         }
         __syncthreads();
@@ -801,8 +808,8 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_bf16_kernel(
             for (int it = 0; it < STRIPE_ITERS; ++it) {
                 const int r = stripe_row(it, rs);
                 if (r < V) {
-                    const f32x4 xa = *reinterpret_cast<const f32x4*>(sm.AX + r * FPAD);
-                    const float2 xb = *reinterpret_cast<const float2*>(sm.AX + r * FPAD + 4);
+                    const f32x4 xa = *reinterpret_cast<const f32x4*>(sm.AX + prow(r) * FPAD);
+                    const float2 xb = *reinterpret_cast<const float2*>(sm.AX + prow(r) * FPAD + 4);
                     f32x4 v = b1;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -821,17 +828,19 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_bf16_kernel(
         // ---- layer 2
         f32x4 acc[6][2];
         stripe_matmul_bf16<NPL>(sm, Bf, lane, acc);
-        load_bfrag<NPL>(Bf, pk + PackedLayout::WB3, wave, lane);            // lands under the layer-2 epilogue
         __syncthreads();
         AQG_STAMP_AT(3)
-        stripe_gather_bf16<NPL, false>(sm, acc, pk + PackedLayout::B2, wave, lane, nullptr);
+        load_bfrag<NPL>(Bf, pk + PackedLayout::WB3, wave, lane);            // lands under the layer-2 epilogue
+        __builtin_amdgcn_sched_barrier(0);
+        stripe_gather_bf16<NPL, false>(sm, acc, bias2, wave, lane, nullptr);
         __syncthreads();
         AQG_STAMP_AT(4)
         // ---- layer 3 + mean pool
         stripe_matmul_bf16<NPL>(sm, Bf, lane, acc);
         __syncthreads();
         AQG_STAMP_AT(5)
-        stripe_gather_bf16<NPL, true>(sm, acc, pk + PackedLayout::B3, wave, lane, pooled + (size_t)b * HID);
+        stripe_gather_bf16<NPL, true>(sm, acc, bias3, wave, lane, pooled + (size_t)b * HID);
+        if (tid < ndw) sm.raw[tid] = rawreg;                                // setup (its only reader) is long done
         __syncthreads();
         AQG_STAMP_AT(6)
 #ifdef AQG_STAMP
@@ -963,9 +972,11 @@ __global__ __launch_bounds__(256) void gcn_heads_kernel(const float* __restrict_
 
 // Trunk variants (aqg_set_option("trunk_variant", v)):
 //   0 exact f32 MFMA, weights resident, 1 workgroup/CU      1 exact f32 MFMA, 2 workgroups/CU
-//   2 exact f32 MFMA, 3 workgroups/CU (spills; kept for A/B) 3 bf16x6 split MFMA (fp32-equivalent), 2/CU  [default]
-//   4 bf16x3 split MFMA (~2^-16 relative per product; still inside the stated tolerance), 2/CU
+//   3 bf16x6 split MFMA (fp32-equivalent), 2/CU  [default]  4 bf16x3 split MFMA (~2^-16 relative per product), 2/CU
+// Measured and dropped this round (slower): 3 workgroups/CU under a 168-VGPR cap (spills), and an 8-wave /
+// 16-column-stripe form at 4 waves per SIMD (spills + doubled A-operand LDS reads): 15.6 M vs 23.3 M boards/s.
 int g_trunk_variant = 3;
+int g_trunk_grid = 0;      // 0 = default persistent grid; otherwise override (diagnostics)
 
 // Diagnostic: fill every CU's LDS with NaN bit patterns so that any read-before-write in a later kernel shows up
 // deterministically (used by the parity tests; LDS contents are otherwise whatever the previous kernel left).
@@ -1032,14 +1043,13 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     } else if (g_trunk_variant == 1) {
         int grid = B < 512 ? B : 512;
         hipLaunchKernelGGL((gcn_trunk_boards_kernel<false, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
-    } else if (g_trunk_variant == 2) {
-        int grid = B < 768 ? B : 768;
-        hipLaunchKernelGGL((gcn_trunk_boards_kernel<false, 3>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
     } else if (g_trunk_variant == 3) {
         int grid = B < 512 ? B : 512;
+        if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
         hipLaunchKernelGGL((gcn_trunk_boards_bf16_kernel<6, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
     } else {
         int grid = B < 512 ? B : 512;
+        if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
         hipLaunchKernelGGL((gcn_trunk_boards_bf16_kernel<3, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
     }
     if (g_profile_trunk) hipEventRecord(prof_event(), st);

@@ -33,7 +33,7 @@ extern "C" {
 
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
-/* tuning knobs: "trunk_variant" 0/1/2 = exact f32-input MFMA with 1/2/3 workgroups per CU, 3 = bf16x6 split MFMA
+/* tuning knobs: "trunk_variant" 0/1 = exact f32-input MFMA with 1/2 workgroups per CU, 3 = bf16x6 split MFMA
  * (fp32-equivalent products, default), 4 = bf16x3 split MFMA; "profile_trunk" 0/1 = event pairs around trunk launches */
 int aqg_set_option(const char* name, int value);
 /* Measurement aid (bench.py): with option "profile_trunk" = 1 a HIP event pair is recorded around every launch of the

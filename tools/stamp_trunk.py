@@ -18,14 +18,14 @@ model = GNNNetwork().to(dev).eval(); pk = model.packed_weights(dev)
 B = 65536
 st = synth_states(B)
 names = ["setup", "L1a gather6", "L1b 6->128", "L2 mfma", "L2 stripe gather", "L3 mfma", "L3 gather+pool", "loop top"]
-for v in (1, 3, 4):
-    _lib.set_option("trunk_variant", v)
+for v, grid in ((3, 256), (3, 512), (4, 256), (4, 512)):
+    _lib.set_option("trunk_variant", v); _lib.set_option("trunk_grid", grid)
     pooled = torch.zeros((B + 1, 128), device=dev)
     for _ in range(3):
         _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, _lib.stream_ptr(dev)), "t")
     torch.cuda.synchronize()
     raw = pooled[B].view(torch.int64)[:9].cpu().tolist()
     n = raw[8]; tot = sum(raw[:8])
-    print(f"variant {v}: boards by WG0 = {n}, cycles/board (s_memtime @100MHz units?) = {tot / max(n,1):.1f}")
+    print(f"variant {v} grid {grid}: boards by WG0 = {n}, cycles/board (s_memtime @100MHz units?) = {tot / max(n,1):.1f}")
     for nm, c in zip(names, raw[:8]):
         print(f"   {nm:18s} {c / max(n,1):10.1f}  {100.0 * c / tot:5.1f}%")
