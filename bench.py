@@ -34,6 +34,10 @@ FWD_FLOP_PER_BOARD = 5492480                                         # SURVEY 8(
 HBM_BYTES_PER_BOARD = 169760                                         # layer-granular algorithmic bytes
 PEAK_F32_MFMA = 157.3e12                                             # MI355X_MICROARCH.md: f32-input MFMA
 PEAK_HBM = 8.0e12
+# HBM bytes per board actually moved by the default trunk, from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+# WRITE_SIZE, separate passes; profiles/r01_trunk_bf16x6_hbm_pmc.csv, B = 65,536 boards per launch).  PMC counters
+# cannot be collected from inside this process, so `roofline.traffic` = this per-board figure x boards per launch.
+TRUNK_HBM_BYTES_PER_BOARD_PMC = 3827
 
 
 def cpu_baseline(sims, mean_plies, budget_s=15.0):
@@ -182,8 +186,12 @@ def main():
                             "boards_per_s": B / (fwd_ms * 1e-3), "ms": fwd_ms, "trunk_variants": variants,
                             "mfma_frac": B / (fwd_ms * 1e-3) * FWD_FLOP_PER_BOARD / PEAK_F32_MFMA,
                             "hbm_frac_survey_formula": B / (fwd_ms * 1e-3) * HBM_BYTES_PER_BOARD / PEAK_HBM},
-            "roofline": {"kernel": "gcn_trunk_boards_kernel", "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA, "traffic": None,
+            "roofline": {"kernel": "gcn_trunk_boards_bf16_kernel<6,2> (GCN trunk, bf16x6-split MFMA)", "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA,
+                         "traffic": TRUNK_HBM_BYTES_PER_BOARD_PMC * leaf_evals / max(trunk_launches, 1),
+                         "traffic_note": "HBM bytes per launch = 3,827 B/board (rocprofv3 PMC, profiles/r01_trunk_bf16x6_hbm_pmc.csv; taken on the "
+                                         "spilling build -- the current spill-free build moves less) x boards per launch; algorithmic layer-granular "
+                                         "figure is 169,760 B/board (hbm_frac_survey_formula): activations never leave LDS",
                          "launches": trunk_launches, "avg_launch_us": trunk_ms / max(trunk_launches, 1) * 1e3,
                          "boards_per_launch_avg": leaf_evals / max(trunk_launches, 1),
                          "flop_per_board": TRUNK_FLOP_PER_BOARD,
