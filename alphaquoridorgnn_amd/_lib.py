@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQG_LIB_PATH", os.path.join(_HERE, "libaqgnn_hip.so"))  # override: diagnostic builds only
 MAX_LEGAL = 136
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c = ctypes
 _vp, _i32, _f32 = _c.c_void_p, _c.c_int32, _c.c_float
@@ -23,7 +23,7 @@ class EngineStruct(_c.Structure):
         [(n, _i32) for n in ("board_size", "num_walls", "plies_for_draw", "num_games", "sims", "node_cap",
                              "max_plies", "prior_mode", "fake_bias")]
         + [("c_puct", _f32), ("temperature", _f32)]
-        + [(n, _vp) for n in ("node_p", "node_w", "node_n", "node_action", "node_kids",
+        + [(n, _vp) for n in ("node_rec",
                               "node_count", "root_state", "path", "path_len",
                               "leaf_flag", "leaf_state",
                               "game_active", "game_plies", "game_result",

@@ -5,11 +5,11 @@
 //                      float32 PUCT arithmetic under NumPy-2 promotion, float64 w accumulators)
 //   self_play.py:40-68 play(): record (state, visit distribution), sample like np.random.choice, next(), z.
 //
-// Layout: one 64-lane wavefront per game.  A game's tree is a flat SoA pool of reference-"Node"s
-// (p, w, n, action, first-child|count); children of a node are contiguous, in State.legal_actions() order,
+// Layout: one 64-lane wavefront per game.  A game's tree is a flat pool of 32-byte reference-"Node" records
+// (w, p, n, first-child|count, action); children of a node are contiguous, in State.legal_actions() order,
 // so the PUCT arg-max is a strided wave reduction and "first maximum wins" is (max score, min index).
 // Child STATES are never stored: the descent re-applies next() from the root's 24-byte packed state, so
-// a node costs 21 bytes instead of the reference's full State copy.
+// a node costs 32 bytes instead of the reference's full State copy.
 // One simulation = fused step kernel (expand/backup of the previous leaf, select, legal actions of the new leaf)
 // -> GNN trunk -> GNN heads on the leaf batch;
 // every game has exactly one leaf in flight, so no virtual loss is needed and per-game semantics equal the
@@ -40,21 +40,32 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     return v;
 }
 
-struct GameCtx {
-    int g, lane;
-    size_t nb;  // node base of this game
+// One reference-"Node" (pv_mcts.py:24-31) per 32-byte record: the statistics, the prior, the action that led here and
+// the child range sit in one cache sector, so a descent level is ONE dependent load round (the chosen child's
+// `kids` and `action` arrive together with its w/n/p).
+struct alignas(32) NodeRec {
+    double w;          // cumulative value (python float in the reference)
+    float p;           // prior
+    int32_t n;         // visit count
+    uint32_t kids;     // first child (24 bits) | child count << 24 ; 0 = unexpanded
+    uint32_t action;   // action that led to this node (0xFF for the root)
+    uint32_t pad[2];
 };
+static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
+
+__device__ __forceinline__ NodeRec* game_nodes(const aqg_engine& e, int g) {
+    return reinterpret_cast<NodeRec*>(e.node_rec) + (size_t)g * e.node_cap;
+}
 
 // Backup (pv_mcts.py:36-42,:49-50,:62-64): every node on the path gets w += value, n += 1 with the sign flipping
 // per ply.  The path nodes are distinct, so lane d updates path[d] independently (one parallel step instead of a
 // serial chain of dependent global read-modify-writes); the sums are the same float64 additions.
-__device__ __forceinline__ void backup_path(const aqg_engine& e, size_t nb, const int* __restrict__ path, int depth,
+__device__ __forceinline__ void backup_path(NodeRec* __restrict__ nodes, const int* __restrict__ path, int depth,
                                             double leaf_value, int lane) {
     for (int d = lane; d <= depth; d += 64) {
-        const size_t idx = nb + path[d];
-        const double v = ((depth - d) & 1) ? -leaf_value : leaf_value;
-        e.node_w[idx] += v;
-        e.node_n[idx] += 1;
+        NodeRec& r = nodes[path[d]];
+        r.w += ((depth - d) & 1) ? -leaf_value : leaf_value;
+        r.n += 1;
     }
 }
 
@@ -98,8 +109,9 @@ __global__ void engine_set_roots_kernel(aqg_engine e, const uint8_t* __restrict_
 __global__ void engine_begin_move_kernel(aqg_engine e) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= e.num_games || !e.game_active[g]) return;
-    const size_t nb = (size_t)g * e.node_cap;
-    e.node_p[nb] = 0.f; e.node_w[nb] = 0.0; e.node_n[nb] = 0; e.node_action[nb] = 0xFF; e.node_kids[nb] = 0;
+    NodeRec root;
+    root.w = 0.0; root.p = 0.f; root.n = 0; root.kids = 0; root.action = 0xFF; root.pad[0] = 0; root.pad[1] = 0;
+    game_nodes(e, g)[0] = root;
     e.node_count[g] = 1;
     const int ply = e.game_plies[g];
     if (e.hist_visits && ply < e.max_plies) {      // clear this ply's dense visit row (filled by finish_move)
@@ -116,7 +128,7 @@ template <int N>
 __device__ __forceinline__ void game_select(const aqg_engine& e, int g, int lane) {
     if (!e.game_active[g]) { if (lane == 0) e.leaf_flag[g] = 0; return; }
     if (lane == 0) e.leaf_flag[g] = 0;
-    const size_t nb = (size_t)g * e.node_cap;
+    NodeRec* __restrict__ nodes = game_nodes(e, g);
     int* path = e.path + (size_t)g * (e.sims + 2);
     QState s = load_state(e.root_state, 1, g);
     int node = 0, depth = 0;
@@ -124,6 +136,7 @@ __device__ __forceinline__ void game_select(const aqg_engine& e, int g, int lane
     if (lane == 0) path[0] = 0;
     int terminal = 0;
     double value = 0.0;
+    uint32_t kids = nodes[0].kids;       // child range of the current node (wave-uniform)
     for (;;) {
         const bool lose = is_lose<N>(s), draw = is_draw(s, e.plies_for_draw);
         if (lose || draw) {                                    // pv_mcts.py:35-42
@@ -131,21 +144,18 @@ __device__ __forceinline__ void game_select(const aqg_engine& e, int g, int lane
             terminal = 1;
             break;
         }
-        const uint32_t kids = e.node_kids[nb + node];
         const int cnt = (int)(kids >> 24), first = (int)(kids & 0xFFFFFF);
         if (cnt == 0) break;                                   // pv_mcts.py:45 unexpanded leaf
-        // pv_mcts.py:69-78 next_child_node
-        int nloc[3]; float ploc[3]; double wloc[3];
+        // pv_mcts.py:69-78 next_child_node: each lane reads up to 3 whole child records
+        NodeRec rec[3];
         int t = 0;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int i = lane + 64 * r;
             if (i < cnt) {
-                nloc[r] = e.node_n[nb + first + i];
-                ploc[r] = e.node_p[nb + first + i];
-                wloc[r] = e.node_w[nb + first + i];
-                t += nloc[r];
-            } else { nloc[r] = 0; ploc[r] = 0.f; wloc[r] = 0.0; }
+                rec[r] = nodes[first + i];
+                t += rec[r].n;
+            } else { rec[r].w = 0.0; rec[r].p = 0.f; rec[r].n = 0; rec[r].kids = 0; rec[r].action = 0; }
         }
         t = wave_sum_i(t);
         const float st = (float)sqrt((double)t);              // f32(math.sqrt(t))
@@ -154,8 +164,8 @@ __device__ __forceinline__ void game_select(const aqg_engine& e, int g, int lane
         for (int r = 0; r < 3; ++r) {
             const int i = lane + 64 * r;
             if (i < cnt) {
-                const float u = ((e.c_puct * ploc[r]) * st) / (float)(1 + nloc[r]);
-                const float q = nloc[r] ? (float)(-wloc[r] / (double)nloc[r]) : 0.0f;
+                const float u = ((e.c_puct * rec[r].p) * st) / (float)(1 + rec[r].n);
+                const float q = rec[r].n ? (float)(-rec[r].w / (double)rec[r].n) : 0.0f;
                 const float sc = q + u;
                 if (sc > best) { best = sc; besti = i; }       // strict > keeps the lowest index within a lane
             }
@@ -167,8 +177,14 @@ __device__ __forceinline__ void game_select(const aqg_engine& e, int g, int lane
             if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
         }
         if (besti == 0x7fffffff) besti = 0;                    // all-NaN guard (np.argmax would return 0)
+        // the winner's kids / action live in lane (besti & 63), slot (besti >> 6)
+        const int slot = besti >> 6, src = besti & 63;
+        const uint32_t k_sel = slot == 0 ? rec[0].kids : (slot == 1 ? rec[1].kids : rec[2].kids);
+        const uint32_t a_sel = slot == 0 ? rec[0].action : (slot == 1 ? rec[1].action : rec[2].action);
+        kids = (uint32_t)__shfl((int)k_sel, src);
+        const int action = __shfl((int)a_sel, src);
         node = first + besti;
-        s = next_state<N>(s, e.node_action[nb + node]);
+        s = next_state<N>(s, action);
         ++depth;
         if (lane == 0) path[depth] = node;
         if (lane == (depth & 63) && depth < 64) mynode = node;
@@ -177,16 +193,16 @@ __device__ __forceinline__ void game_select(const aqg_engine& e, int g, int lane
         // backup (pv_mcts.py:36-42): lane d updates the node at depth d from its register copy; the (practically
         // unreachable) part of a path deeper than 63 is finished by lane 0 from its own path[] stores
         if (lane <= depth) {
-            const size_t idx = nb + mynode;
-            e.node_w[idx] += ((depth - lane) & 1) ? -value : value;
-            e.node_n[idx] += 1;
+            NodeRec& r = nodes[mynode];
+            r.w += ((depth - lane) & 1) ? -value : value;
+            r.n += 1;
         }
         if (lane == 0) {
             e.stat_terminal_sims[g] += 1;
             for (int d = 64; d <= depth; ++d) {
-                const size_t idx = nb + path[d];
-                e.node_w[idx] += ((depth - d) & 1) ? -value : value;
-                e.node_n[idx] += 1;
+                NodeRec& r = nodes[path[d]];
+                r.w += ((depth - d) & 1) ? -value : value;
+                r.n += 1;
             }
         }
     } else {
@@ -256,7 +272,7 @@ template <int N>
 __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, int lane) {
     constexpr int A = Geo<N>::A;
     if (e.leaf_flag[g] != 1) return;
-    const size_t nb = (size_t)g * e.node_cap;
+    NodeRec* __restrict__ nodes = game_nodes(e, g);
     const int* path = e.path + (size_t)g * (e.sims + 2);
     const int depth = e.path_len[g];
     const int leaf = path[depth];
@@ -289,17 +305,17 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
         for (int r = 0; r < 3; ++r) {
             const int i = lane + 64 * r;
             if (i < cnt) {
-                const size_t idx = nb + first + i;
-                e.node_p[idx] = pl[r]; e.node_w[idx] = 0.0; e.node_n[idx] = 0;
-                e.node_action[idx] = ord[i]; e.node_kids[idx] = 0;
+                NodeRec c;
+                c.w = 0.0; c.p = pl[r]; c.n = 0; c.kids = 0; c.action = ord[i]; c.pad[0] = 0; c.pad[1] = 0;
+                nodes[first + i] = c;
             }
         }
     }
     if (lane == 0 && first + cnt <= e.node_cap && cnt > 0) {
-        e.node_kids[nb + leaf] = (uint32_t)first | ((uint32_t)cnt << 24);
+        nodes[leaf].kids = (uint32_t)first | ((uint32_t)cnt << 24);
         e.node_count[g] = first + cnt;
     }
-    backup_path(e, nb, path, depth, (double)e.value[g], lane);   // value.item() -> python float
+    backup_path(nodes, path, depth, (double)e.value[g], lane);   // value.item() -> python float
     if (lane == 0) e.stat_leaf_evals[g] += 1;   // per-game slot: a shared counter would serialise 2048 atomics per step
 }
 
@@ -335,8 +351,8 @@ __global__ __launch_bounds__(256) void engine_finish_move_kernel(aqg_engine e, c
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= e.num_games || !e.game_active[g]) return;
-    const size_t nb = (size_t)g * e.node_cap;
-    const uint32_t kids = e.node_kids[nb];
+    const NodeRec* __restrict__ nodes = game_nodes(e, g);
+    const uint32_t kids = nodes[0].kids;
     const int cnt = (int)(kids >> 24), first = (int)(kids & 0xFFFFFF);
     const int ply = e.game_plies[g];
     QState s = load_state(e.root_state, 1, g);
@@ -346,7 +362,7 @@ __global__ __launch_bounds__(256) void engine_finish_move_kernel(aqg_engine e, c
         uint8_t* hs = e.hist_state72 + ((size_t)g * e.max_plies + ply) * STATE72;
         if (lane == 0) pack72(s, N, hs);
         uint16_t* hv = e.hist_visits + ((size_t)g * e.max_plies + ply) * A;
-        for (int i = lane; i < cnt; i += 64) hv[e.node_action[nb + first + i]] = (uint16_t)e.node_n[nb + first + i];
+        for (int i = lane; i < cnt; i += 64) hv[nodes[first + i].action] = (uint16_t)nodes[first + i].n;
     }
     if (lane != 0) return;
 
@@ -355,32 +371,32 @@ __global__ __launch_bounds__(256) void engine_finish_move_kernel(aqg_engine e, c
         int idx = 0;
         if (e.temperature == 0.f) {                            // one-hot at the first maximum, then choice(p=one-hot)
             int bestn = -1;
-            for (int i = 0; i < cnt; ++i) { const int n = e.node_n[nb + first + i]; if (n > bestn) { bestn = n; idx = i; } }
+            for (int i = 0; i < cnt; ++i) { const int n = nodes[first + i].n; if (n > bestn) { bestn = n; idx = i; } }
         } else {
             // boltzman (pv_mcts.py:106-109): xs = n ** (1/T); p = x / sum(xs).  T == 1 is exact (n ** 1.0 == float(n)).
             const double invT = 1.0 / (double)e.temperature;
             double tot = 0.0;
             for (int i = 0; i < cnt; ++i) {
-                const double x = (double)e.node_n[nb + first + i];
+                const double x = (double)nodes[first + i].n;
                 tot += (e.temperature == 1.f) ? x : pow(x, invT);
             }
             // np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, side='right')
             double last = 0.0;
             for (int i = 0; i < cnt; ++i) {
-                const double x = (double)e.node_n[nb + first + i];
+                const double x = (double)nodes[first + i].n;
                 last += ((e.temperature == 1.f) ? x : pow(x, invT)) / tot;
             }
             const double u = uniforms[g];
             double acc = 0.0;
             idx = 0;
             for (int i = 0; i < cnt; ++i) {
-                const double x = (double)e.node_n[nb + first + i];
+                const double x = (double)nodes[first + i].n;
                 acc += ((e.temperature == 1.f) ? x : pow(x, invT)) / tot;
                 if (acc / last <= u) idx = i + 1;
             }
             if (idx >= cnt) idx = cnt - 1;
         }
-        chosen = e.node_action[nb + first + idx];
+        chosen = (int)nodes[first + idx].action;
     }
     if (chosen < 0) {
         // Dead end: legal_actions() is empty.  The reference would re-predict forever-leaf and np.random.choice([])
@@ -410,12 +426,12 @@ __global__ __launch_bounds__(256) void engine_root_visits_kernel(aqg_engine e, i
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= e.num_games) return;
-    const size_t nb = (size_t)g * e.node_cap;
-    const uint32_t kids = e.node_kids[nb];
+    const NodeRec* __restrict__ nodes = game_nodes(e, g);
+    const uint32_t kids = nodes[0].kids;
     const int cnt = (int)(kids >> 24), first = (int)(kids & 0xFFFFFF);
     for (int i = lane; i < MAX_LEGAL; i += 64) {
-        visits[(size_t)g * MAX_LEGAL + i] = (i < cnt) ? e.node_n[nb + first + i] : 0;
-        actions[(size_t)g * MAX_LEGAL + i] = (i < cnt) ? e.node_action[nb + first + i] : 0xFF;
+        visits[(size_t)g * MAX_LEGAL + i] = (i < cnt) ? nodes[first + i].n : 0;
+        actions[(size_t)g * MAX_LEGAL + i] = (i < cnt) ? (uint8_t)nodes[first + i].action : 0xFF;
     }
     if (lane == 0) count[g] = cnt;
 }

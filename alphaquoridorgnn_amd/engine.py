@@ -40,11 +40,7 @@ class BatchedSelfPlay:
             return torch.zeros(shape, dtype=dtype, device=dev)
 
         t = self.t = {}
-        t["node_p"] = z((G * cap,), torch.float32)
-        t["node_w"] = z((G * cap,), torch.float64)
-        t["node_n"] = z((G * cap,), torch.int32)
-        t["node_action"] = z((G * cap,), torch.uint8)
-        t["node_kids"] = z((G * cap,), torch.int32)
+        t["node_rec"] = z((G * cap, 4), torch.float64)     # 32-byte node records (csrc/mcts.hip NodeRec)
         t["node_count"] = z((G,), torch.int32)
         t["root_state"] = z((G, 24), torch.uint8)
         t["path"] = z((G, self.sims + 2), torch.int32)
@@ -80,7 +76,7 @@ class BatchedSelfPlay:
         e.prior_mode = 0 if evaluator == "gnn" else 1
         e.fake_bias = int(fake_bias)
         e.c_puct, e.temperature = float(c_puct), float(temperature)
-        for name in ("node_p", "node_w", "node_n", "node_action", "node_kids", "node_count", "root_state", "path",
+        for name in ("node_rec", "node_count", "root_state", "path",
                      "path_len", "leaf_flag", "leaf_state", "game_active", "game_plies", "game_result", "legal_order",
                      "legal_count", "pooled", "policy", "value", "hist_state72", "hist_visits", "hist_action", "counters",
                      "stat_leaf_evals", "stat_terminal_sims", "packed_weights"):

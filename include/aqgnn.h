@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define AQG_MAX_LEGAL 136 /* >= 5 pawn moves + 128 wall placements */
-#define AQG_ABI_VERSION 1
+#define AQG_ABI_VERSION 2
 
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
@@ -119,8 +119,8 @@ typedef struct aqg_engine {
     int32_t fake_bias;
     float c_puct;             /* 1.25  pv_mcts.py:71 */
     float temperature;        /* SP_TEMPERATURE self_play.py:20; 1.0 exact, 0 = argmax */
-    /* tree pools, [G * node_cap] */
-    float* node_p; double* node_w; int32_t* node_n; uint8_t* node_action; uint32_t* node_kids;
+    /* tree pool: [G * node_cap] 32-byte node records {f64 w, f32 p, i32 n, u32 first_child|count<<24, u32 action, pad} */
+    void* node_rec;
     /* per game, [G] */
     int32_t* node_count; uint8_t* root_state /* [G,24] */; int32_t* path /* [G, sims+2] */; int32_t* path_len;
     uint8_t* leaf_flag /* [G] 1 = this simulation's leaf needs an evaluation */; uint8_t* leaf_state /* [G,24] */;

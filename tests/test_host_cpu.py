@@ -28,7 +28,7 @@ def test_capi_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} not bound in _lib.SIGNATURES"
     assert lib.aqg_abi_version() == _lib.ABI_VERSION
     assert lib.aqg_gcn_packed_floats(9) > 64082          # all 64,082 parameters + padding + fragment copies
-    assert ctypes.sizeof(_lib.EngineStruct) == 9 * 4 + 2 * 4 + 4 + 26 * 8   # 11 scalars (+4 pad) + 26 pointers
+    assert ctypes.sizeof(_lib.EngineStruct) == 9 * 4 + 2 * 4 + 4 + 22 * 8   # 11 scalars (+4 pad) + 22 pointers
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -103,11 +103,24 @@ def test_weight_packing_layout():
     off = 128 * 8 + 128
     W2T = out[off:off + 128 * 128].reshape(128, 128)
     assert np.array_equal(W2T, p["gcn_layers.1.lin.weight"].T)
-    wf2 = out[n - 2 * 128 * 128:n - 128 * 128].reshape(4, 2, 8, 64, 4)     # [wave][ntile][s4][lane][i]
+    WF2, WB2 = 67396, 100164                                               # offsets documented in include/aqgnn.h / gcn_forward.hip
+    assert n == WB2 + 2 * 3 * 128 * 128 // 2
+    wf2 = out[WF2:WF2 + 128 * 128].reshape(4, 2, 8, 64, 4)                 # [wave][ntile][s4][lane][i]
     for (w, j, s4, lane, i) in [(0, 0, 0, 0, 0), (3, 1, 7, 63, 3), (2, 0, 5, 17, 2), (1, 1, 2, 40, 1)]:
         c, q = lane & 15, lane >> 4
         k = (q & 1) * 64 + (q >> 1) * 32 + 4 * s4 + i
         assert wf2[w, j, s4, lane, i] == p["gcn_layers.1.lin.weight"][32 * w + 16 * j + c, k]
+    # bf16 3-way split fragments: hi + mid + lo reproduces the f32 weight to ~2^-24 relative
+    wb2 = out[WB2:WB2 + 3 * 128 * 128 // 2].view(np.uint32).reshape(3, 4, 2, 4, 64, 4)   # [plane][wave][ntile][kb][lane][dword]
+    def bf(u16):
+        return (np.uint32(u16) << np.uint32(16)).view(np.float32)
+    for (w, j, kb, lane, d) in [(0, 0, 0, 0, 0), (3, 1, 3, 63, 3), (1, 0, 2, 21, 1)]:
+        c, q = lane & 15, lane >> 4
+        nn, k = 32 * w + 16 * j + c, 32 * kb + 8 * q + 2 * d
+        for half, kk in ((0, k), (1, k + 1)):
+            parts = [bf((int(wb2[pl, w, j, kb, lane, d]) >> (16 * half)) & 0xFFFF) for pl in range(3)]
+            ref = p["gcn_layers.1.lin.weight"][nn, kk]
+            assert abs(float(parts[0]) + float(parts[1]) + float(parts[2]) - float(ref)) <= 2.0 ** -22 * abs(float(ref)) + 1e-30
 
 
 _GLOO_WORKER = r'''
