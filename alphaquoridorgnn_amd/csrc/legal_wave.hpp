@@ -17,14 +17,55 @@ __device__ __forceinline__ int wave_legal_actions(const QState& s, int lane, uin
                                                   uint8_t* __restrict__ order) {
     constexpr int V = Geo<N>::V, NW = Geo<N>::NW, A = Geo<N>::A;
     const Open base = make_open<N>(s.hw, s.vw);
-    bool legH = false, legV = false;
+    // Step 1 (lane = wall slot): geometric placement and the touch-count prefilter.  A placeable candidate that
+    // the prefilter clears is legal outright (game_logic.py:327-328); the others need the two path searches.
+    bool placeH = false, placeV = false, needH = false, needV = false;
     if (s.pwl > 0 && lane < NW) {
         uint64_t hp, vp;
         placeable_masks<N>(s.hw, s.vw, hp, vp);
-        if ((hp >> lane) & 1) legH = wall_keeps_paths<N>(s, base, 1, lane);
-        if ((vp >> lane) & 1) legV = wall_keeps_paths<N>(s, base, 2, lane);
+        placeH = (hp >> lane) & 1;
+        placeV = (vp >> lane) & 1;
+        needH = placeH && possibly_blocking<N>(s.hw, s.vw, 1, lane);
+        needV = placeV && possibly_blocking<N>(s.hw, s.vw, 2, lane);
     }
-    const uint64_t mH = __ballot(legH), mV = __ballot(legV);
+    const uint64_t pH = __ballot(placeH), pV = __ballot(placeV), nH = __ballot(needH), nV = __ballot(needV);
+    // Step 2 (lane = task): the searches are dealt out evenly -- task 2k / 2k+1 = the mover's / the enemy's flood
+    // fill for the k-th candidate that needs them (H candidates in slot order, then V) -- so no lane runs more
+    // than one fill per round, instead of up to four on the lane that owns a doubly-suspicious slot.
+    const int cH = __popcll(nH), cV = __popcll(nV);
+    const int ntask = 2 * (cH + cV);
+    uint64_t failH = 0, failV = 0;
+    for (int tbase = 0; tbase < ntask; tbase += 64) {
+        const int task = tbase + lane;
+        uint64_t myfailH = 0, myfailV = 0;
+        if (task < ntask) {
+            const int k = task >> 1;
+            const int orient = k < cH ? 1 : 2;
+            uint64_t m = orient == 1 ? nH : nV;
+            int rank = orient == 1 ? k : k - cH;
+            int slot = 0;                                   // position of the rank-th set bit of m
+#pragma unroll
+            for (int w = 32; w >= 1; w >>= 1) {
+                const uint64_t lowmask = (1ull << w) - 1;
+                const int c = __popcll((m >> slot) & lowmask);
+                if (rank >= c) { rank -= c; slot += w; }
+            }
+            const Open o = add_wall<N>(base, orient, slot);
+            const int me = s.ppos, other = V - 1 - s.epos;
+            const bool ok = (task & 1) == 0 ? can_reach<N>(o, me, other, mask_row<N>(0))
+                                            : can_reach<N>(o, other, me, mask_row<N>(N - 1));
+            if (!ok) { if (orient == 1) myfailH = 1ull << slot; else myfailV = 1ull << slot; }
+        }
+        // wave-wide OR of the failure bits
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            myfailH |= ((uint64_t)(uint32_t)__shfl_xor((int)(myfailH >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)myfailH, off);
+            myfailV |= ((uint64_t)(uint32_t)__shfl_xor((int)(myfailV >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)myfailV, off);
+        }
+        failH |= myfailH; failV |= myfailV;
+    }
+    const uint64_t mH = pH & ~failH, mV = pV & ~failV;
+    const bool legH = (mH >> lane) & 1, legV = (mV >> lane) & 1;
 
     uint8_t pawn[8];
     const int npawn = legal_pos_list<N>(base, s.ppos, V - 1 - s.epos, pawn);
