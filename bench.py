@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--sims", type=int, default=200, help="MCTS simulations per move")
     ap.add_argument("--gnn-batch", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--large-games", type=int, default=16384,
+                    help="extra single-GPU leg: one generation at this many concurrent games (north star: >= 10k); 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,6 +160,19 @@ def main():
         variants[name] = {"boards_per_s": B / (ms * 1e-3), "ms": ms}
     _lib.set_option("trunk_variant", 3)
 
+    large = None
+    if world == 1 and args.large_games > 0:
+        del eng
+        torch.cuda.empty_cache()
+        eng = BatchedSelfPlay(model, num_games=args.large_games, sims=args.sims, seed=77)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        c, _ = one_step(False)
+        torch.cuda.synchronize()
+        dt = time.time() - t1
+        large = {"workload": f"one generation, {args.large_games} concurrent games x {args.sims} sims/move, 1 GPU (untimed-warmup-free single step)",
+                 "games_per_s": c["finished"] / dt, "s_per_generation": dt, "leaf_evals_per_s": c["leaf_evals"] / dt}
+
     if rank == 0:
         achieved = leaf_evals * TRUNK_FLOP_PER_BOARD / (trunk_ms * 1e-3) if trunk_ms > 0 else 0.0   # rank 0's launches
         boards_per_s_kernel = leaf_evals / (trunk_ms * 1e-3) if trunk_ms > 0 else 0.0
@@ -203,6 +218,8 @@ def main():
                                  "issues 6 x 96/81 times that (bf16_mfma_issued_tflops vs 2.5 PFLOP/s). Activations never leave LDS: real "
                                  "HBM traffic is ~24 B in + 512 B out per board"},
         }
+        if large is not None:
+            out["large_batch"] = large
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.sims, mean_plies)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()

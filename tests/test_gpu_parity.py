@@ -301,3 +301,41 @@ def test_selfplay_generation_with_gnn(dev):
         else:
             assert zz[0] == 0
         off += p
+
+
+# ------------------------------------------------------------------ drop-in surface (reference-shaped calls)
+def test_dropin_surface_play_and_policy(dev, tmp_path, monkeypatch):
+    """The reference's call surface end to end on the GPU: pv_mcts_policy / pv_mcts_action on a State, self_play.play()
+    history schema (self_play.py:51-54,:63-66), write_data() pickle (self_play.py:30-37), create_network()."""
+    import pickle
+    from alphaquoridorgnn_amd import pv_mcts, self_play, pv_network_gnn
+    from alphaquoridorgnn_amd.game_logic import State
+    model, _ = _model(0)
+    monkeypatch.setattr(pv_mcts, "PV_EVALUATE_COUNT", 16)
+    s = State()
+    la = s.legal_actions()
+    pol = pv_mcts.pv_mcts_policy(model, s, 1.0, "cuda")
+    assert len(pol) == len(la) and abs(sum(pol) - 1.0) < 1e-12 and min(pol) >= 0
+    assert round(sum(p * 15 for p in pol)) == 15                      # visit counts sum to sims - 1
+    onehot = pv_mcts.pv_mcts_policy(model, s, 0, "cuda")
+    assert sorted(onehot)[-1] == 1 and sum(onehot) == 1
+    a = pv_mcts.pv_mcts_action(model, 1.0, "cuda")(s)
+    assert int(a) in la
+    monkeypatch.setattr(pv_mcts, "PV_EVALUATE_COUNT", 6)
+    hist = self_play.play(model, "cuda")
+    assert 1 <= len(hist) <= 116
+    st0, pi0, z0 = hist[0]
+    assert st0 == State().to_array() and len(pi0) == 209 and abs(sum(pi0) - 1.0) < 1e-12 and z0 in (-1, 0, 1)
+    assert all(h[2] == (z0 if i % 2 == 0 else -z0) for i, h in enumerate(hist))
+    monkeypatch.chdir(tmp_path)
+    path = self_play.write_data(hist)
+    with open(path, "rb") as f:                                       # our own file: plain pickle of python lists
+        back = pickle.load(f)
+    assert back == hist
+    monkeypatch.setattr(pv_network_gnn, "PV_NETWORK_PATH", str(tmp_path / "models/GNN/9x9") + "/")
+    pv_network_gnn.create_network()
+    net = pv_network_gnn.GNNNetwork()
+    net.prep_for_inference(str(tmp_path / "models/GNN/9x9/best.pth"))
+    p, v = net.predict(State(), "cuda")
+    assert p.shape == (131,) and abs(float(p.sum()) - 1) < 1e-5 and -1 <= v <= 1
+    assert net.name == "GNN" and net.preprocess_input([State().to_array()]).shape == (1, 72)
