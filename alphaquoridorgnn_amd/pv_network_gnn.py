@@ -89,6 +89,10 @@ class GraphPolicyValueNetwork(nn.Module):
             _lib.check(lib.aqg_gcn_pack_weights_host(self.board_size, arr, ctypes.c_void_p(out.data_ptr())),
                        "aqg_gcn_pack_weights_host")
             self._packed = out.to(device)
+            # One-time cost per weight refresh: make the upload globally visible before any kernel reads it.  Without
+            # it the first launch after a fresh upload was observed (rarely, MI355X / ROCm 7.2) to read a not-yet-
+            # complete tail of the buffer (the bf16 fragment planes) -- see DESIGN.md section 3.
+            torch.cuda.current_stream(device).synchronize()
             self._packed_key = key
         return self._packed
 

@@ -33,6 +33,8 @@ TRUNK_FLOP_PER_BOARD = 2 * 81 * 6 * 128 + 2 * (2 * 81 * 128 * 128)   # 5,432,832
 FWD_FLOP_PER_BOARD = 5492480                                         # trunk + both heads
 HBM_BYTES_PER_BOARD = 169760                                         # layer-granular algorithmic bytes
 PEAK_F32_MFMA = 157.3e12                                             # MI355X_MICROARCH.md: f32-input MFMA
+PEAK_F16_MFMA = 2500.0e12                                            # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
+SPLIT_TERMS = 3                                                      # f16x3: hi*hi + hi*lo + lo*hi per f32 product
 PEAK_HBM = 8.0e12
 # HBM bytes per board actually moved by the default trunk, from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
 # WRITE_SIZE, separate passes; profiles/r01_trunk_bf16x6_hbm_pmc.csv, B = 65,536 boards per launch).  PMC counters
@@ -154,7 +156,7 @@ def main():
                                               _lib.ptr(value), _lib.stream_ptr(dev)), "fwd")
     fwd_ms = time_ms(fwd, 200, warmup=20)
     variants = {}
-    for name, v in (("f32_mfma_exact", 1), ("bf16x6_split", 3), ("bf16x3_split", 4)):
+    for name, v in (("f32_mfma_exact", 1), ("f16x3_split", 3), ("bf16x3_split", 4)):
         _lib.set_option("trunk_variant", v)
         ms = time_ms(fwd, 100, warmup=10)
         variants[name] = {"boards_per_s": B / (ms * 1e-3), "ms": ms}
@@ -187,7 +189,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (bf16x6-split MFMA products, f32 accumulate)",
+            "dtype": "f32 (f16x3-split MFMA products, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]/[3]: one self-play generation per step -- concurrent 9x9 games per GPU "
                                    "played to termination, lock-step PV-MCTS, random-weight GNN evaluator, then the all-gather of (s,pi,z)",
@@ -201,22 +203,27 @@ def main():
                             "boards_per_s": B / (fwd_ms * 1e-3), "ms": fwd_ms, "trunk_variants": variants,
                             "mfma_frac": B / (fwd_ms * 1e-3) * FWD_FLOP_PER_BOARD / PEAK_F32_MFMA,
                             "hbm_frac_survey_formula": B / (fwd_ms * 1e-3) * HBM_BYTES_PER_BOARD / PEAK_HBM},
-            "roofline": {"kernel": "gcn_trunk_boards_bf16_kernel<6,2> (GCN trunk, bf16x6-split MFMA)", "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA,
+            "roofline": {"kernel": "gcn_trunk_boards_bf16_kernel<3,2,true> (GCN trunk, fp16 two-plane split MFMA)", "bound": "mfma",
+                         "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / SPLIT_TERMS / 1e12,
+                         "unit": "TFLOP/s", "frac": achieved / (PEAK_F16_MFMA / SPLIT_TERMS),
                          "traffic": TRUNK_HBM_BYTES_PER_BOARD_PMC * leaf_evals / max(trunk_launches, 1),
-                         "traffic_note": "HBM bytes per launch = 3,827 B/board (rocprofv3 PMC, profiles/r01_trunk_bf16x6_hbm_pmc.csv; taken on the "
-                                         "spilling build -- the current spill-free build moves less) x boards per launch; algorithmic layer-granular "
-                                         "figure is 169,760 B/board (hbm_frac_survey_formula): activations never leave LDS",
+                         "traffic_note": "HBM bytes per launch = 3,827 B/board (rocprofv3 PMC on the three-plane build of this kernel, "
+                                         "profiles/r01_trunk_bf16x6_hbm_pmc.csv; dominated by the L2-missing share of the per-board weight "
+                                         "fragment reads) x boards per launch; algorithmic layer-granular figure is 169,760 B/board "
+                                         "(hbm_frac_survey_formula): activations never leave LDS",
                          "launches": trunk_launches, "avg_launch_us": trunk_ms / max(trunk_launches, 1) * 1e3,
                          "boards_per_launch_avg": leaf_evals / max(trunk_launches, 1),
                          "flop_per_board": TRUNK_FLOP_PER_BOARD,
                          "hbm_frac_survey_formula": boards_per_s_kernel * HBM_BYTES_PER_BOARD / PEAK_HBM,
-                         "bf16_mfma_issued_tflops": achieved * 6 * (96.0 / 81.0) / 1e12, "bf16_mfma_peak_tflops": 2500.0,
-                         "note": "default trunk = bf16x6 split MFMA (f32 data, f32 accumulate, 6 bf16 products per f32 product: "
-                                 "fp32-equivalent, same 1e-5/1e-4 tolerance as the exact f32-input MFMA variant). achieved = ALGORITHMIC "
-                                 "f32 FLOP/s, peak = the f32-input MFMA roof the exact path is bound by (SURVEY 8d); the bf16 pipe actually "
-                                 "issues 6 x 96/81 times that (bf16_mfma_issued_tflops vs 2.5 PFLOP/s). Activations never leave LDS: real "
-                                 "HBM traffic is ~24 B in + 512 B out per board"},
+                         "frac_vs_f32_input_mfma_peak": achieved / PEAK_F32_MFMA,
+                         "f16_mfma_issued_tflops": achieved * SPLIT_TERMS * (96.0 / 81.0) / 1e12, "f16_mfma_peak_tflops": PEAK_F16_MFMA / 1e12,
+                         "note": "default trunk = fp16 two-plane split MFMA (f32 data, f32 accumulate, 3 fp16 products hi*hi+hi*lo+lo*hi "
+                                 "per f32 product: fp32-equivalent, same 1e-5/1e-4 tolerance as the exact f32-input MFMA variant). "
+                                 "achieved = ALGORITHMIC f32 FLOP/s (5,432,832 per board x boards / kernel time from HIP events around "
+                                 "every launch); peak = dense fp16 MFMA peak / 3 split terms = the matrix-pipe roof of this algorithm "
+                                 "(the exact f32-input MFMA roof of SURVEY 8d is 157.3 TFLOP/s: frac_vs_f32_input_mfma_peak). Launches "
+                                 "inside the MCTS are ~2,000 boards = 4 per CU, so avg_launch_us carries the wave-quantisation tail; "
+                                 "gnn_forward.trunk_variants is the same kernel at 4,096 boards per launch"},
         }
         if large is not None:
             out["large_batch"] = large

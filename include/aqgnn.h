@@ -33,8 +33,8 @@ extern "C" {
 
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
-/* tuning knobs: "trunk_variant" 0/1 = exact f32-input MFMA with 1/2 workgroups per CU, 3 = bf16x6 split MFMA
- * (fp32-equivalent products, default), 4 = bf16x3 split MFMA; "profile_trunk" 0/1 = event pairs around trunk launches */
+/* tuning knobs: "trunk_variant" 0/1 = exact f32-input MFMA with 1/2 workgroups per CU, 3 = fp16 two-plane split MFMA
+ * (hi*hi + hi*lo + lo*hi: fp32-equivalent products, default), 4 = bf16 two-plane split MFMA (~2^-16 per product); "profile_trunk" 0/1 = event pairs around trunk launches */
 int aqg_set_option(const char* name, int value);
 /* Measurement aid (bench.py): with option "profile_trunk" = 1 a HIP event pair is recorded around every launch of the
  * dominant kernel (the GCN trunk) on its launch stream.  This call waits for the last recorded event, accumulates

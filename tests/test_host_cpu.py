@@ -104,7 +104,8 @@ def test_weight_packing_layout():
     W2T = out[off:off + 128 * 128].reshape(128, 128)
     assert np.array_equal(W2T, p["gcn_layers.1.lin.weight"].T)
     WF2, WB2 = 67396, 100164                                               # offsets documented in include/aqgnn.h / gcn_forward.hip
-    assert n == WB2 + 2 * 3 * 128 * 128 // 2
+    WH2 = WB2 + 2 * 3 * 128 * 128 // 2
+    assert n == WH2 + 2 * 2 * 128 * 128 // 2
     wf2 = out[WF2:WF2 + 128 * 128].reshape(4, 2, 8, 64, 4)                 # [wave][ntile][s4][lane][i]
     for (w, j, s4, lane, i) in [(0, 0, 0, 0, 0), (3, 1, 7, 63, 3), (2, 0, 5, 17, 2), (1, 1, 2, 40, 1)]:
         c, q = lane & 15, lane >> 4
@@ -121,6 +122,17 @@ def test_weight_packing_layout():
             parts = [bf((int(wb2[pl, w, j, kb, lane, d]) >> (16 * half)) & 0xFFFF) for pl in range(3)]
             ref = p["gcn_layers.1.lin.weight"][nn, kk]
             assert abs(float(parts[0]) + float(parts[1]) + float(parts[2]) - float(ref)) <= 2.0 ** -22 * abs(float(ref)) + 1e-30
+    # fp16 2-way split fragments (default trunk): hi = RNE_f16(w), lo = RNE_f16(w - hi)
+    for L, key in ((0, "gcn_layers.1.lin.weight"), (1, "gcn_layers.2.lin.weight")):
+        wh = out[WH2 + L * 128 * 128:WH2 + (L + 1) * 128 * 128].view(np.uint16).reshape(2, 4, 2, 4, 64, 8)   # [plane][wave][ntile][kb][lane][8 halves]
+        W = p[key].astype(np.float32)
+        hi = W.astype(np.float16)
+        lo = (W - hi.astype(np.float32)).astype(np.float16)
+        wv, j, kb, lane, e = np.meshgrid(np.arange(4), np.arange(2), np.arange(4), np.arange(64), np.arange(8), indexing="ij")
+        nn, kk = 32 * wv + 16 * j + (lane & 15), 32 * kb + 8 * (lane >> 4) + e
+        assert np.array_equal(wh[0], hi[nn, kk].view(np.uint16)) and np.array_equal(wh[1], lo[nn, kk].view(np.uint16))
+        rec = hi.astype(np.float64) + lo.astype(np.float64)
+        assert np.max(np.abs(rec - W)) <= 2.0 ** -22 * np.max(np.abs(W))
 
 
 _GLOO_WORKER = r'''

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Cold-launch determinism check for the GCN trunk ("LDS above 128 KB").
+
+Each fresh process uploads weights, launches the trunk 40 times on the same 300 boards (300 > 256 CUs, so some
+CUs hold a second resident workgroup) and compares every launch with the last one bit-for-bit and the first one
+with the fp64 oracle.  Run several fresh processes: the failure this guards against showed only on the first
+launches of a process.  Usage: cold_launch_check.py [variant=3] [processes=8]
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def child(variant):
+    import numpy as np
+    import torch
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+    from oracle import gnn as og
+    from tests import _util as U
+    dev = _lib.require_gpu("cuda:0")
+    lib = _lib.load()
+    _lib.set_option("trunk_variant", variant)
+    g = U.golden("walk_9x9.npz")
+    B = 300
+    recs = g["states"][np.linspace(0, g["states"].shape[0] - 1, B).astype(int)]
+    params = og.init_params(0)
+    m = GNNNetwork()
+    m.load_state_dict({k: torch.from_numpy(x.copy()) for k, x in params.items()})
+    m = m.to("cuda").eval()
+    pk = m.packed_weights(dev)
+    st = torch.from_numpy(recs).to(dev)
+    outs = []
+    for _ in range(40):
+        pooled = torch.full((B, 128), float("nan"), device=dev)
+        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None,
+                                              _lib.stream_ptr(dev)), "trunk")
+        outs.append(pooled)
+    torch.cuda.synchronize()
+    bad = [i for i, o in enumerate(outs) if not torch.equal(o, outs[-1])]
+    ref = og.forward_states(params, recs)["pooled"]
+    err = float(np.max(np.abs(outs[0].cpu().numpy().astype(np.float64) - ref)))
+    print(f"variant {variant}: launches differing from the last: {bad[:8]} ({len(bad)}/40); first launch vs fp64 oracle max|d pooled| = {err:.3e}")
+    return 1 if bad or not err < 1e-5 else 0
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        sys.exit(child(int(sys.argv[2])))
+    variant = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    procs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    fails = 0
+    for _ in range(procs):                       # one GPU process at a time
+        fails += subprocess.call([sys.executable, os.path.abspath(__file__), "--child", str(variant)]) != 0
+    print(f"cold-launch check: {fails}/{procs} processes failed")
+    sys.exit(1 if fails else 0)
