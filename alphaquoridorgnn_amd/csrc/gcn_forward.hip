@@ -46,30 +46,17 @@ struct PackedLayout {
     // MFMA B-fragment order of W2^T / W3^T: [wave 4][ntile 2][s4 8][lane 64][4]  (see load_wfrag)
     static constexpr size_t WF2 = VB2 + 4;
     static constexpr size_t WF3 = WF2 + HID * HID;
-    // bf16 3-way split (hi, mid, lo) of W2^T / W3^T in 16x16x32 MFMA B-fragment order, stored as raw dwords:
-    // [plane 3][wave 4][ntile 2][kblock 4][lane 64][4 dwords = 8 bf16]   (see load_bfrag)
-    static constexpr size_t WB2 = WF3 + HID * HID;
-    static constexpr size_t WB3 = WB2 + 3 * HID * HID / 2;
-    // fp16 2-way split (hi, lo) of W2^T / W3^T, same fragment order: [plane 2][wave 4][ntile 2][kblock 4][lane 64][4 dwords]
-    static constexpr size_t WH2 = WB3 + 3 * HID * HID / 2;
+    // fp16 2-way split (hi, lo) of W2^T / W3^T in 16x16x32 MFMA B-fragment order, stored as raw dwords:
+    // [plane 2][tile 8 (16 columns each)][kblock 4][lane 64][4 dwords = 8 fp16]   (see load_bfrag_mm)
+    static constexpr size_t WH2 = WF3 + HID * HID;
     static constexpr size_t WH3 = WH2 + 2 * HID * HID / 2;
-    static constexpr size_t TOTAL = WH3 + 2 * HID * HID / 2;
+    // layer-1 weight as fp16 B fragments with the split folded into the k dimension: per lane 8 halves,
+    // k-slots 0..7 = hi(W1[n][0..5]),0,0   8..15 = lo(W1[n][0..5]),0,0   16..31 = 0:  [tile 8][lane 64][4 dwords]
+    static constexpr size_t WH1 = WH3 + 2 * HID * HID / 2;
+    static constexpr size_t TOTAL = WH1 + 4 * 2 * 64 * 4;
 };
 
 size_t packed_floats() { return PackedLayout::TOTAL; }
-
-// round-to-nearest-even f32 -> bf16 (host side of the split; the device uses v_cvt_pk_bf16_f32, also RNE)
-static inline uint16_t host_bf16_rn(float x) {
-    uint32_t u; memcpy(&u, &x, 4);
-    u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-    return (uint16_t)u;
-}
-static inline float host_bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
-static inline void host_split3(float x, uint16_t (&pl)[3]) {
-    pl[0] = host_bf16_rn(x); float r = x - host_bf16_to_f32(pl[0]);
-    pl[1] = host_bf16_rn(r); r = r - host_bf16_to_f32(pl[1]);
-    pl[2] = host_bf16_rn(r);
-}
 
 // tensors (host fp32), state_dict order: gcn0.w[H,F] gcn0.b gcn1.w[H,H] gcn1.b gcn2.w gcn2.b
 // pol0.w[H/2,H] pol0.b pol2.w[A,H/2] pol2.b val0.w[H/2,H] val0.b val2.w[1,H/2] val2.b
@@ -98,24 +85,6 @@ int pack_weights_host(int N, const float* const* t, float* out) {
                         out[PackedLayout::WF2 + o] = t[2][n * HID + k];
                         out[PackedLayout::WF3 + o] = t[4][n * HID + k];
                     }
-    for (int L = 0; L < 2; ++L) {
-        const float* W = t[L == 0 ? 2 : 4];                       // [n][k]
-        uint32_t* dst = reinterpret_cast<uint32_t*>(out + (L == 0 ? PackedLayout::WB2 : PackedLayout::WB3));
-        for (int w = 0; w < 4; ++w)
-            for (int j = 0; j < 2; ++j)
-                for (int kb = 0; kb < 4; ++kb)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int d = 0; d < 4; ++d) {
-                            const int c = lane & 15, q = lane >> 4, n = 32 * w + 16 * j + c;
-                            uint16_t a[3], b[3];
-                            host_split3(W[n * HID + 32 * kb + 8 * q + 2 * d], a);
-                            host_split3(W[n * HID + 32 * kb + 8 * q + 2 * d + 1], b);
-                            for (int pl = 0; pl < 3; ++pl) {
-                                const size_t o = (((((size_t)pl * 4 + w) * 2 + j) * 4 + kb) * 64 + lane) * 4 + d;
-                                dst[o] = (uint32_t)a[pl] | ((uint32_t)b[pl] << 16);
-                            }
-                        }
-    }
     for (int L = 0; L < 2; ++L) {                                 // fp16 split planes
         const float* W = t[L == 0 ? 2 : 4];
         uint32_t* dst = reinterpret_cast<uint32_t*>(out + (L == 0 ? PackedLayout::WH2 : PackedLayout::WH3));
@@ -138,6 +107,26 @@ int pack_weights_host(int N, const float* const* t, float* out) {
                                 dst[o] = (uint32_t)a[pl] | ((uint32_t)b[pl] << 16);
                             }
                         }
+    }
+    {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(out + PackedLayout::WH1);
+        for (int w = 0; w < 4; ++w)
+            for (int j = 0; j < 2; ++j)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int d = 0; d < 4; ++d) {
+                        const int c = lane & 15, q = lane >> 4, n = 32 * w + 16 * j + c;
+                        uint16_t h[2] = {0, 0};
+                        for (int e = 0; e < 2; ++e) {
+                            const int k = 2 * d + e;
+                            if (q < 2 && k < F) {
+                                const float x = t[0][n * F + k];
+                                const _Float16 hi = (_Float16)x;
+                                const _Float16 v = (q == 0) ? hi : (_Float16)(x - (float)hi);
+                                memcpy(&h[e], &v, 2);
+                            }
+                        }
+                        dst[((w * 2 + j) * 64 + lane) * 4 + d] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+                    }
     }
     for (int u = 0; u < HID / 2; ++u)
         for (int k = 0; k < HID; ++k) {
@@ -170,11 +159,13 @@ __device__ __forceinline__ float dinv_of_bits(int bits) { return dinv_of(1 + __p
 // Diagnostic build only (-DAQG_STAMP, never shipped): per-phase s_memtime sums of workgroup 0 / wave 0 are
 // written behind the pooled rows (pooled + B*128, as 16 x u64).  In the real kernel no stamp executes.
 #ifdef AQG_STAMP
-#define AQG_STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int st_n = 0;
+#define AQG_STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int st_n = 0;
+#define AQG_STAMP_VMWAIT(i) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); AQG_STAMP_AT(i) }
 #define AQG_STAMP_AT(i) { unsigned long long st_now = __builtin_readcyclecounter(); st_sum[i] += st_now - st_prev; st_prev = st_now; }
 #else
 #define AQG_STAMP_DECL
 #define AQG_STAMP_AT(i)
+#define AQG_STAMP_VMWAIT(i)
 #endif
 
 struct alignas(16) TrunkSmem {
@@ -513,81 +504,22 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_kernel(const
 #ifdef AQG_STAMP
     if (blockIdx.x == 0 && tid == 0) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(pooled + (size_t)B * HID);
-        for (int i = 0; i < 8; ++i) o[i] = st_sum[i];
-        o[8] = (unsigned long long)st_n;
+        for (int i = 0; i < 16; ++i) o[i] = st_sum[i];
+        o[16] = (unsigned long long)st_n;
     }
 #endif
 }
 
-// =============================================================================================
-// split-precision trunk: the same network with the two 128x128 contractions on the 16-bit matrix pipe.
-// Every f32 operand x is split into 16-bit planes (each the RNE of the running remainder) and the product is
-// rebuilt from partial products accumulated in f32 by v_mfma_f32_16x16x32_{f16,bf16} (8 passes per 16x16x32 tile =
-// 16x the f32-input MFMA rate):
-//   fp16 planes, x = hi + lo (11 + 11 mantissa bits):  a*b ~= hi*hi + hi*lo + lo*hi      [default, "f16x3"]
-//       the dropped lo*lo term is ~2^-22 |ab|: fp32-equivalent for this network (logits within 1.1e-7 of the exact
-//       f32 path offline, i.e. the same distance the exact f32 path has from the fp64 oracle).  Activations here are
-//       O(1) after ReLU/normalised aggregation and |W| < 1, far inside fp16 range; lo underflows to fp16 subnormals
-//       only below |x| ~ 2^-14 * 2^-11, where the absolute error (< 2^-25) is irrelevant for O(1) sums.
-//   bf16 planes, x = hi + lo' (8 + 8 bits):            a*b ~= hi*hi + hi*lo' + lo'*hi    ["bf16x3", ~2^-16 |ab|]
-//   bf16 planes, x = hi + mid + lo: six terms (NT = 6), fp32-equivalent, three planes -- compiled only in
-//       diagnostic builds, see the note at g_trunk_variant.
-// All variants stay inside the stated 1e-5 / 1e-4 tolerance against the fp64 oracle (tests/test_gpu_parity.py).
-// The image lives in LDS as 16-bit planes [plane][81][136]; the split is done ONCE per element in the stripe
-// epilogue (non-redundant), the MFMA phase reads ready-made fragments with ds_read_b128.
-// =============================================================================================
-// Diagnostic builds only (never shipped; DESIGN.md 3 "LDS above 128 KB"): -DAQG_PAD_X3_FRONT pushes the two-plane
-// image up by one plane so the second-resident workgroup's plane 1 lies above 128 KB of the CU's LDS (reproduces the
-// cold-launch stale reads); -DAQG_DIAG_SITES=<mask> adds a fence + double barrier at the marked hand-off sites.
-#ifdef AQG_DIAG_SITES
-#define AQG_DIAG_FENCE_AT(bit) do { if ((AQG_DIAG_SITES) & (bit)) { __threadfence_block(); __syncthreads(); __builtin_amdgcn_s_waitcnt(0); __syncthreads(); } } while (0)
-#else
-#define AQG_DIAG_FENCE_AT(bit) do {} while (0)
-#endif
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int PROW = 272;                    // plane row stride in bytes: 128 bf16 + 16 B pad (17 slots of 16 B: odd)
-constexpr int PPLANE = 81 * PROW + 48;       // plane stride (22,080 B): == 4 (mod 16) slots -> conflict-free stripe reads
-
-// Row permutation for the small per-row tables (coef, AX): rows handled by one instruction are r = it + 8*rs, i.e.
-// 8 apart; with 32-byte rows that is a 256-byte stride = every lane group on the same banks (4-way conflicts).
-// Class-major order puts the rows of one iteration next to each other instead.
-__device__ __forceinline__ int prow(int r) { return (r & 7) * 11 + (r >> 3); }   // 0..87 for r in 0..80
-
-template <int NPL>
-struct alignas(16) TrunkSmemB {
-#ifdef AQG_PAD_X3_FRONT
-    alignas(16) unsigned char diag_front[NPL == 2 ? 22080 : 16];   // diagnostic: push the x3 planes up so P[1] of the
-                                                                    // second-resident workgroup straddles 128 KB
-#endif
-    alignas(16) unsigned char P[NPL][PPLANE];   // bf16 planes of the activation image; a wave's stripe bytes of
-                                                // planes 0/1 double as its parked f32 XW stripe
-    alignas(16) float X0[81 * FPAD];
-    alignas(16) float AX[88 * FPAD];            // indexed by prow(r)
-    alignas(16) float coef[88][8];              // indexed by prow(r)
-    int obits[96];
-    unsigned int raw[20];                       // next board's record, staged by <= 18 lanes (1 VGPR instead of 18)
-};
-
-__device__ __forceinline__ unsigned int pack_bf16x2(__bf16 a, __bf16 b) {
-    return (unsigned int)__builtin_bit_cast(unsigned short, a) | ((unsigned int)__builtin_bit_cast(unsigned short, b) << 16);
-}
-
-// split 4 f32 values into NPL bf16 planes and store them as 8 bytes per plane at byte offset `off` of each plane.
-// Written on packed pairs so it compiles to v_cvt_pk_bf16_f32 / v_pk_add_f32: ~18 vector instructions per 4 values.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int cvt_pk_bf16(float a, float b) {          // RNE, low half = a
-    return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){a, b}, bf16x2));
-}
-__device__ __forceinline__ f32x4 bf16_pairs_to_f32(unsigned int p01, unsigned int p23) {
-    return (f32x4){__builtin_bit_cast(float, p01 << 16), __builtin_bit_cast(float, p01 & 0xFFFF0000u),
-                   __builtin_bit_cast(float, p23 << 16), __builtin_bit_cast(float, p23 & 0xFFFF0000u)};
-}
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int PROW = 272;                    // plane row stride in bytes: 128 fp16 + 16 B pad (17 slots of 16 B: odd ->
+                                             // the 16-lane ds_read_b128 groups of an A fragment hit distinct bank slots)
+constexpr int PPLANE = 81 * PROW + 48;       // plane stride (22,080 B)
+
 __device__ __forceinline__ unsigned int cvt_pk_f16(float a, float b) {            // RNE, low half = a
     return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){a, b}, f16x2));
 }
@@ -596,331 +528,356 @@ __device__ __forceinline__ f32x4 f16_pairs_to_f32(unsigned int p01, unsigned int
     const f32x2 b = __builtin_convertvector(__builtin_bit_cast(f16x2, p23), f32x2);
     return (f32x4){a[0], a[1], b[0], b[1]};
 }
-template <int NPL, bool F16, typename SM>
-__device__ __forceinline__ void store_split4(SM& sm, int off, const f32x4 v) {
-    if (F16) {     // fp16 planes: hi (11 bits) + lo (next 11 bits) = 22 mantissa bits in two planes
-        const unsigned int h01 = cvt_pk_f16(v[0], v[1]), h23 = cvt_pk_f16(v[2], v[3]);
-        const f32x4 r1 = v - f16_pairs_to_f32(h01, h23);
-        *reinterpret_cast<u32x2*>(&sm.P[0][off]) = (u32x2){h01, h23};
-        *reinterpret_cast<u32x2*>(&sm.P[1][off]) = (u32x2){cvt_pk_f16(r1[0], r1[1]), cvt_pk_f16(r1[2], r1[3])};
-        return;
-    }
-    const unsigned int h01 = cvt_pk_bf16(v[0], v[1]), h23 = cvt_pk_bf16(v[2], v[3]);
-    const f32x4 r1 = v - bf16_pairs_to_f32(h01, h23);
-    const unsigned int m01 = cvt_pk_bf16(r1[0], r1[1]), m23 = cvt_pk_bf16(r1[2], r1[3]);
+__device__ __forceinline__ f32x4 mfma_f16(const u32x4 a, const u32x4 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// =============================================================================================
+// all-MFMA trunk (default): linear maps AND neighbourhood aggregation on the 16-bit matrix pipe, fp32-equivalent.
+//   GCNConv:  H' = relu( D^-1/2 (A + I) D^-1/2 (H W) + b )          (pv_network_gnn.py:55-57 + PyG gcn_norm)
+// Split precision: every f32 operand x is held as two fp16 numbers, hi = RNE16(x), lo = RNE16(x - hi) (11 + 11
+// mantissa bits), and a product is rebuilt as hi*hi + hi*lo + lo*hi, accumulated in f32 by
+// v_mfma_f32_16x16x32_f16 (16x the f32-input MFMA rate).  The dropped lo*lo term is ~2^-22 |ab|: logits land within
+// 1e-7 of the exact-f32 kernel, i.e. at the distance the exact-f32 kernel itself has from the fp64 oracle.
+// Activations are O(1) after ReLU / normalised aggregation and |W| < 1: far inside fp16 range.
+// 1. Z = H W per wave column stripe: A fragments = fp16 hi/lo planes of H in LDS ([plane][node][feature], read with
+//    ds_read_b128), B fragments = host-split W in registers, 3 terms per 16x16x32 block.
+// 2. Z' = dinv (.) Z in f32, split into fp16 hi/lo IN REGISTERS.  The accumulator layout of a 16x16 tile (lane =
+//    column c, 4 consecutive rows per lane) is also a legal A-operand layout (lane = row of A, 8 consecutive k per
+//    lane) for the TRANSPOSED product  Y^T = Z'^T (A + I): the k index (= node) is simply enumerated in the order
+//    the accumulators hold it, k-slot (q, e) <-> node 32 kb + 16 (e >> 2) + 4 q + (e & 3), and the adjacency B
+//    fragments are built in that same order.  (A + I) is 0/1 -- exact in fp16 -- so the product needs two terms
+//    (hi, lo), and it is banded (|k - n| in {0, 1, 9}): 10 of the 18 (k-block, node-tile) blocks are non-zero.
+// 3. The transposed result has lane = node, 4 consecutive features per lane: exactly the 8-byte packed store of
+//    the plane image (or, for the last layer, the per-lane partial of the mean pool).  No parking of f32 tiles in
+//    LDS, no VALU gather, no separate layer-1 gather: layer 1 is  X0 W1  (one MFMA per tile: the six features and
+//    the hi/lo split of W1 share one 32-deep k block, X0 is exact in fp16) followed by the same aggregation.
+// Per wave and board: 12 + 2 x 144 MFMAs for the linear maps + 3 x 40 for the aggregation.
+// =============================================================================================
+constexpr int AF_BLOCKS = 10;
+// non-zero (k-block, node-tile) blocks of the banded adjacency, 2 / 3 bits per entry, block 0 in the low bits:
+//   kb = {0,0,1,0,1,1,2,1,2,2}   nt = {0,1,1,2,2,3,3,4,4,5}
+constexpr unsigned int AF_KB_PACK = 0u | (0u << 2) | (1u << 4) | (0u << 6) | (1u << 8) | (1u << 10) | (2u << 12) | (1u << 14) | (2u << 16) | (2u << 18);
+constexpr unsigned int AF_NT_PACK = 0u | (1u << 3) | (1u << 6) | (2u << 9) | (2u << 12) | (3u << 15) | (3u << 18) | (4u << 21) | (4u << 24) | (5u << 27);
+constexpr int af_kb(int blk) { return (AF_KB_PACK >> (2 * blk)) & 3; }
+constexpr int af_nt(int blk) { return (AF_NT_PACK >> (3 * blk)) & 7; }
+
+struct alignas(16) TrunkSmemM {
+    alignas(16) unsigned char P[2][PPLANE];            // fp16 hi / lo planes of the activation image [node][feature]
+    alignas(16) unsigned int AF[AF_BLOCKS][64][4];     // (A + I) B fragments of this board (fp16 0 / 1)
+    alignas(16) unsigned int X0[96][4];                // node features as 8 fp16 (6 used); rows 81..95 stay zero
+    alignas(16) float dinv[96];                        // deg^-1/2 per node; entries 81..95 stay zero
+    alignas(16) float bias[3][HID];
+    unsigned int raw[20];                              // next board's record
+};
+static_assert(2 * sizeof(TrunkSmemM) <= 160 * 1024, "two workgroups per CU");
+
+__device__ __forceinline__ float row16_sum(float x) {     // sum over the 16 lanes of a DPP row, result in every lane
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));   // row_ror:8
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));   // row_ror:4
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false));   // row_ror:2
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return x;
+}
+
+// Weight fragments are fetched with buffer loads: one SGPR resource for the packed buffer, one shared VGPR (lane * 16)
+// and a scalar offset per load -- no 64-bit address VGPRs (they were the first thing the allocator spilled, and a
+// spilled address is reloaded behind an s_waitcnt vmcnt(0) that serialises the whole prefetch).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t packed_rsrc(const float* pk) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pk), 0, (int)(PackedLayout::TOTAL * sizeof(float)), 0x00020000);
+}
+__device__ __forceinline__ u32x4 load_frag16(__amdgpu_buffer_rsrc_t rs, int lane16, int byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, byte_off, 0);
+}
+
+// A wave owns JT 16-column feature tiles: JT = 2 -> 4 waves per board, JT = 1 -> 8 waves per board.
+// fp16 planes of four consecutive features of one node: hi (11 bits) + lo (next 11 bits) = 22 mantissa bits
+__device__ __forceinline__ void store_split4(TrunkSmemM& sm, int off, const f32x4 v) {
+    const unsigned int h01 = cvt_pk_f16(v[0], v[1]), h23 = cvt_pk_f16(v[2], v[3]);
+    const f32x4 r1 = v - f16_pairs_to_f32(h01, h23);
     *reinterpret_cast<u32x2*>(&sm.P[0][off]) = (u32x2){h01, h23};
-    *reinterpret_cast<u32x2*>(&sm.P[1][off]) = (u32x2){m01, m23};
-    if (NPL == 3) {
-        const f32x4 r2 = r1 - bf16_pairs_to_f32(m01, m23);
-        *reinterpret_cast<u32x2*>(&sm.P[2][off]) = (u32x2){cvt_pk_bf16(r2[0], r2[1]), cvt_pk_bf16(r2[2], r2[3])};
-    }
+    *reinterpret_cast<u32x2*>(&sm.P[1][off]) = (u32x2){cvt_pk_f16(r1[0], r1[1]), cvt_pk_f16(r1[2], r1[3])};
 }
 
-// B fragments: Bf[pl][j][kb] = 8 bf16 of plane pl: W[k = 32*kb + 8*q + 0..7][n = 32*wave + 16*j + c]
-template <int NPL>
-__device__ __forceinline__ void load_bfrag(u32x4 (&Bf)[NPL][2][4], const float* __restrict__ WB, int wave, int lane) {
-    const u32x4* base = reinterpret_cast<const u32x4*>(WB) + (size_t)__builtin_amdgcn_readfirstlane(wave) * (2 * 4 * 64) + lane;
+template <int JT>
+__device__ __forceinline__ void load_bfrag_mm(u32x4 (&Bf)[2][JT][4], __amdgpu_buffer_rsrc_t rs, size_t region, int wave, int lane) {
+    const int base = (int)(region * sizeof(float)) + wave * (JT * 4 * 64 * 16);
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl)
+    for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < JT; ++j)
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) Bf[pl][j][kb] = base[(size_t)pl * (4 * 2 * 4 * 64) + (j * 4 + kb) * 64];
+            for (int kb = 0; kb < 4; ++kb) Bf[pl][j][kb] = load_frag16(rs, lane * 16, base + (pl * (8 * 4 * 64) + (j * 4 + kb) * 64) * 16);
 }
 
-// MFMA phase: six 16-row tiles (rows >= 81 of the last tile are clamped to row 80 and discarded) x four 32-deep
-// k blocks; per (tile, block) NPL ds_read_b128 feed 2*NT MFMAs, smallest terms first.
-template <bool F16>
-__device__ __forceinline__ f32x4 mfma_split(const u32x4 a, const u32x4 b, const f32x4 c) {
-    if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-template <int NPL, bool F16, typename SM>
-__device__ __forceinline__ void stripe_matmul_bf16(const SM& sm, const u32x4 (&Bf)[NPL][2][4], int lane, f32x4 (&acc)[6][2]) {
+// Z = H W for this wave's columns: six 16-row tiles (tile 5 = row 80 repeated) x four 32-deep k blocks, A fragments
+// double-buffered from the planes, three fp16 terms per block (smallest first).
+template <int JT>
+__device__ __forceinline__ void stripe_matmul_mm(const TrunkSmemM& sm, const u32x4 (&Bf)[2][JT][4], int lane, f32x4 (&acc)[6][JT]) {
     const int c = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int m = 0; m < 6; ++m) {
-        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    u32x4 cur[NPL], nxt[NPL];
-    const int row5 = (80 + c) > 80 ? 80 : 80 + c;           // tile 5: rows 80 + c clamped to 80
+    for (int m = 0; m < 6; ++m)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 cur[2], nxt[2];
     auto frag_off = [&](int step) -> int {                  // step = m*4 + kb
         const int m = step >> 2, kb = step & 3;
-        const int row = (m < 5) ? 16 * m + c : row5;
+        const int row = (m < 5) ? 16 * m + c : 80;
         return row * PROW + 64 * kb + 16 * q;
     };
     {
         const int o = frag_off(0);
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) cur[pl] = *reinterpret_cast<const u32x4*>(&sm.P[pl][o]);
+        cur[0] = *reinterpret_cast<const u32x4*>(&sm.P[0][o]);
+        cur[1] = *reinterpret_cast<const u32x4*>(&sm.P[1][o]);
     }
 #pragma unroll
     for (int step = 0; step < 24; ++step) {
         const int m = step >> 2, kb = step & 3;
         if (step < 23) {
             const int o = frag_off(step + 1);
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) nxt[pl] = *reinterpret_cast<const u32x4*>(&sm.P[pl][o]);
+            nxt[0] = *reinterpret_cast<const u32x4*>(&sm.P[0][o]);
+            nxt[1] = *reinterpret_cast<const u32x4*>(&sm.P[1][o]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < JT; ++j) {
             f32x4 a = acc[m][j];
-            if (NPL == 3) {
-                a = mfma_split<F16>(cur[2], Bf[0][j][kb], a);
-                a = mfma_split<F16>(cur[0], Bf[NPL - 1][j][kb], a);
-                a = mfma_split<F16>(cur[1], Bf[1][j][kb], a);
-            }
-            a = mfma_split<F16>(cur[1], Bf[0][j][kb], a);      // smallest terms first
-            a = mfma_split<F16>(cur[0], Bf[1][j][kb], a);
-            a = mfma_split<F16>(cur[0], Bf[0][j][kb], a);
+            a = mfma_f16(cur[1], Bf[0][j][kb], a);
+            a = mfma_f16(cur[0], Bf[1][j][kb], a);
+            a = mfma_f16(cur[0], Bf[0][j][kb], a);
             acc[m][j] = a;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (step < 23) {
+        if (step < 23) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
+    }
+}
+
+// aggregation part 1 (touches no plane bytes): Z' = dinv (.) Z -> fp16 hi/lo A fragments -> Y^T = Z'^T (A + I)
+template <int JT>
+__device__ __forceinline__ void adj_matmul(const TrunkSmemM& sm, const f32x4 (&acc)[6][JT], int lane, f32x4 (&out)[6][JT]) {
+    const int q = lane >> 4;
+    u32x4 zh[3][JT], zl[3][JT];
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) cur[pl] = nxt[pl];
+    for (int m = 0; m < 6; ++m) {
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(&sm.dinv[16 * m + 4 * q]);   // 0 beyond node 80: clears tile 5's duplicate rows
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            const f32x4 z = acc[m][j] * d4;
+            const unsigned int h01 = cvt_pk_f16(z[0], z[1]), h23 = cvt_pk_f16(z[2], z[3]);
+            const f32x4 r = z - f16_pairs_to_f32(h01, h23);
+            zh[m >> 1][j][2 * (m & 1)] = h01; zh[m >> 1][j][2 * (m & 1) + 1] = h23;
+            zl[m >> 1][j][2 * (m & 1)] = cvt_pk_f16(r[0], r[1]); zl[m >> 1][j][2 * (m & 1) + 1] = cvt_pk_f16(r[2], r[3]);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) out[nt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int blk = 0; blk < AF_BLOCKS; ++blk) {
+        const int kb = af_kb(blk), nt = af_nt(blk);
+        const u32x4 af = *reinterpret_cast<const u32x4*>(&sm.AF[blk][lane][0]);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            out[nt][j] = mfma_f16(zl[kb][j], af, out[nt][j]);
+            out[nt][j] = mfma_f16(zh[kb][j], af, out[nt][j]);
         }
     }
 }
 
-// stripe epilogue on the bf16 image: park XW (f32) in this wave's bytes of planes 0/1, gather + bias + ReLU,
-// then write the result back as split planes (or mean-pool when LAST).
-template <int NPL, bool F16, bool LAST, typename SM>
-__device__ __forceinline__ void stripe_gather_bf16(SM& sm, const f32x4 (&acc)[6][2], const f32x4 bias,
-                                                   int wave, int lane, float* __restrict__ pooled_out) {
-    {
-        const int c = lane & 15, q = lane >> 4;
-        const int o = (4 * q) * PROW + 64 * wave + 4 * c;
+// aggregation part 2: H' = relu(dinv_n * Y + b) -> split planes (lane = node, 4 consecutive features), or the mean pool
+template <int JT, bool LAST>
+__device__ __forceinline__ void adj_store(TrunkSmemM& sm, const f32x4 (&out)[6][JT], int layer, int wave, int lane,
+                                          float* __restrict__ pooled_out) {
+    const int c = lane & 15, q = lane >> 4;
+    const int col0 = 16 * JT * wave + 4 * q;
+    f32x4 bias4[JT];
 #pragma unroll
-        for (int m = 0; m < 5; ++m)
+    for (int j = 0; j < JT; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(&sm.bias[layer][col0 + 16 * j]);
+    f32x4 sum[JT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<float*>(&sm.P[0][o + (16 * m + i) * PROW]) = acc[m][0][i];
-                *reinterpret_cast<float*>(&sm.P[1][o + (16 * m + i) * PROW]) = acc[m][1][i];
+    for (int j = 0; j < JT; ++j) sum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) {
+        const int node = 16 * nt + c;
+        const float dn = sm.dinv[node];
+        const bool live = (nt < 5) || (c == 0);                              // node < 81
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            f32x4 v = out[nt][j] * dn + bias4[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            if (LAST) {
+                if (live) sum[j] += v;
+            } else {
+                if (live) store_split4(sm, node * PROW + 2 * (col0 + 16 * j), v);
             }
-        if (q == 0) {
-            *reinterpret_cast<float*>(&sm.P[0][80 * PROW + 64 * wave + 4 * c]) = acc[5][0][0];
-            *reinterpret_cast<float*>(&sm.P[1][80 * PROW + 64 * wave + 4 * c]) = acc[5][1][0];
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    const int cg = lane & 7, rs = lane >> 3;
-    const int colb = 32 * wave + 4 * cg;
-    f32x4 out[STRIPE_ITERS];
-    const unsigned char* pbase = &sm.P[cg >> 2][0] + 64 * wave + 16 * (cg & 3);   // parked f32 x4 of columns colb..colb+3
-    const unsigned char* p1 = pbase + rs * 8 * PROW;
-    const unsigned char* p2 = pbase + (64 + rs) * PROW;
-    const float* k1 = &sm.coef[rs][0];                  // iteration it < 8: prow(it + 8*rs) = it*11 + rs
-    const float* k2 = &sm.coef[rs * 11 + 8][0];         // iteration 8: prow(64 + rs) = rs*11 + 8; iteration 9: +1
-    const int offU1 = rs == 0 ? 0 : -9 * PROW;
+    if (LAST) {
 #pragma unroll
-    for (int it = 0; it < STRIPE_ITERS; ++it) {
-        const unsigned char *ps, *pu, *pd, *pl, *pr;
-        const float* pk;
-        if (it < 8) {
-            ps = p1 + it * PROW; pk = k1 + it * 11 * 8;
-            pu = (it == 0) ? (rs <= 1 ? ps : ps - 9 * PROW) : ps + offU1;   // rows it + 8*rs < 9: rs == 0, and row 8 (it 0, rs 1)
-            pd = ps + 9 * PROW; pr = ps + PROW;
-            pl = (it == 0) ? (rs == 0 ? ps : ps - PROW) : ps - PROW;
-        } else if (it == 8) {
-            ps = p2; pk = k2; pu = ps - 9 * PROW; pd = ps + 9 * PROW; pl = ps - PROW; pr = ps + PROW;
-        } else if (it == 9) {
-            ps = p2 + 8 * PROW; pk = k2 + 8; pu = ps - 9 * PROW; pd = ps; pl = ps - PROW; pr = ps + PROW;
-        } else {
-            ps = pbase + 80 * PROW; pk = &sm.coef[prow(80)][0]; pu = ps - 9 * PROW; pd = ps; pl = ps - PROW; pr = ps;
+        for (int j = 0; j < JT; ++j) {
+            f32x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = row16_sum(sum[j][e]) * (1.0f / 81.0f);
+            if (c == 0) *reinterpret_cast<f32x4*>(pooled_out + col0 + 16 * j) = t;
         }
-        const f32x4 k4 = *reinterpret_cast<const f32x4*>(pk);
-        const float kr = pk[4];
-        const f32x4 hs = *reinterpret_cast<const f32x4*>(ps);
-        const f32x4 hu = *reinterpret_cast<const f32x4*>(pu);
-        const f32x4 hd = *reinterpret_cast<const f32x4*>(pd);
-        const f32x4 hl = *reinterpret_cast<const f32x4*>(pl);
-        const f32x4 hr = *reinterpret_cast<const f32x4*>(pr);
-        f32x4 v = bias + k4[0] * hs + k4[1] * hu + k4[2] * hd + k4[3] * hl + kr * hr;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        out[it] = v;
-        if (it & 1) __builtin_amdgcn_sched_barrier(0);
-    }
-    if (!LAST) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < STRIPE_ITERS; ++it) {
-            const int r = stripe_row(it, rs);
-            if (r < 81) store_split4<NPL, F16>(sm, r * PROW + 2 * colb, out[it]);
-        }
-    } else {
-        f32x4 sum = out[0];
-#pragma unroll
-        for (int it = 1; it < STRIPE_ITERS - 1; ++it) sum += out[it];
-        if (rs == 0) sum += out[STRIPE_ITERS - 1];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = sum[e];
-            x += __shfl_xor(x, 8); x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
-            sum[e] = x * (1.0f / 81.0f);
-        }
-        if (rs == 0) *reinterpret_cast<f32x4*>(pooled_out + colb) = sum;
     }
 }
 
-// NT = MFMA terms per product block: 6 (bf16 hi/mid/lo, 3 planes) or 3 (2 planes).  F16 selects fp16 planes instead of
-// bf16: hi + lo then carry 22 mantissa bits, so NT = 3 with fp16 is fp32-equivalent with only TWO planes.
-template <int NT, int WGS_PER_CU, bool F16>
-__global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_bf16_kernel(const void* __restrict__ states, int fmt, int B,
-                                                                                 const float* __restrict__ pk,
-                                                                                 float* __restrict__ pooled,
-                                                                                 const uint8_t* __restrict__ active) {
+__device__ __forceinline__ uint32_t bit_of64(uint64_t m, int s) {             // bit s of a wave-uniform 64-bit mask
+    const uint32_t w = (s & 32) ? (uint32_t)(m >> 32) : (uint32_t)m;
+    return (w >> (s & 31)) & 1u;
+}
+
+// (hipcc's second launch-bound argument is waves per SIMD: workgroups per CU x waves per workgroup / 4 SIMDs)
+template <int JT, int WGS_PER_CU>
+__global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trunk_boards_mm_kernel(const void* __restrict__ states, int fmt, int B,
+                                                                                        const float* __restrict__ pk,
+                                                                                        float* __restrict__ pooled,
+                                                                                        const uint8_t* __restrict__ active, int phase_delay) {
     constexpr int N = 9, V = 81, S = 8;
-    constexpr int NPL = (NT == 6) ? 3 : 2;
-    __shared__ TrunkSmemB<NPL> sm;
+    constexpr int NWV = 8 / JT, NTHR = 64 * NWV;
+    __shared__ TrunkSmemM sm;
+    // The two workgroups resident on a CU run identical phase sequences; a start offset for the second-resident ones
+    // (phase_delay x 64 cycles) keeps one on the matrix pipe while the other does vector work.
+    if (blockIdx.x >= 256) for (int i = 0; i < phase_delay; ++i) __builtin_amdgcn_s_sleep(1);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: wave-derived offsets stay in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
 
     const int ndw = fmt == 0 ? 18 : 6;
     int b = blockIdx.x;
     while (b < B && active && !active[b]) b += gridDim.x;
     if (b < B && tid < ndw) sm.raw[tid] = reinterpret_cast<const uint32_t*>(states)[(size_t)b * ndw + tid];
+    // once per workgroup: padding rows that no board ever writes, and the three bias vectors
+    for (int i = tid; i < 96 * 4; i += NTHR) (&sm.X0[0][0])[i] = 0u;
+    if (tid < 96) sm.dinv[tid] = 0.f;
+    for (int i = tid; i < 3 * HID; i += NTHR) {
+        const int L = i >> 7, k = i & 127;
+        sm.bias[L][k] = pk[(L == 0 ? PackedLayout::B1 : L == 1 ? PackedLayout::B2 : PackedLayout::B3) + k];
+    }
     __syncthreads();
-    u32x4 Bf[NPL][2][4];
+    u32x4 Bf[2][JT][4];
+    const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
 
     AQG_STAMP_DECL
     while (b < B) {
         AQG_STAMP_AT(7)
-        // Global loads are issued right AFTER a barrier, never just before one: __syncthreads() waits vmcnt(0), so a
-        // load issued ahead of it exposes its whole L2 latency, while one issued behind it lands under the next phase.
-        // vmcnt retires in order: a small load issued AFTER a prefetch can only be waited for by draining the whole
-        // prefetch, so the per-layer biases are fetched first and handed to the gathers by value.
-        const f32x4 bias2 = *reinterpret_cast<const f32x4*>(pk + PackedLayout::B2 + 32 * wave + 4 * (lane & 7));
-        const f32x4 bias3 = *reinterpret_cast<const f32x4*>(pk + PackedLayout::B3 + 32 * wave + 4 * (lane & 7));
-        load_bfrag<NPL>(Bf, pk + (F16 ? PackedLayout::WH2 : PackedLayout::WB2), wave, lane);            // lands under setup + layer 1
-        __builtin_amdgcn_sched_barrier(0);                                  // keep the loads at the phase start
-        // ---- setup step 1: node features + this tile's open-edge bits
-        if (tid < V) {
-            QState s;
-            if (fmt == 0) {
-                uint64_t h = 0, v = 0;
+        // loads first (they land under the setup); vmcnt retires in order, so the small layer-1 fragment goes ahead
+        u32x4 w1f[JT];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const uint32_t x = sm.raw[1 + i];
-                    h |= (uint64_t)gather_bit0_x4(x) << (4 * i);
-                    v |= (uint64_t)gather_bit0_x4(x >> 1) << (4 * i);
-                }
-                s.hw = h; s.vw = v;
+        for (int j = 0; j < JT; ++j) w1f[j] = load_frag16(rs, lane * 16, (int)(PackedLayout::WH1 * sizeof(float)) + (wave * JT + j) * (64 * 16));
+        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- setup.  The record becomes wave-uniform scalars (the wall masks by ballot over the 64 wall bytes), the
+        //      open-edge bitboards are computed once per wave on the scalar unit, lanes only extract their bits.
+        {
+            uint64_t hw, vw;
+            uint32_t hd;
+            if (fmt == 0) {
+                const uint32_t wb = reinterpret_cast<const uint8_t*>(sm.raw)[4 + lane];   // wall byte of slot `lane`: bit0 H, bit1 V
+                hw = __ballot((wb & 1u) != 0);
+                vw = __ballot((wb & 2u) != 0);
+                hd = __builtin_amdgcn_readfirstlane(sm.raw[0]);
             } else {
-                s.hw = (uint64_t)sm.raw[0] | ((uint64_t)sm.raw[1] << 32);
-                s.vw = (uint64_t)sm.raw[2] | ((uint64_t)sm.raw[3] << 32);
+                hw = (uint64_t)__builtin_amdgcn_readfirstlane(sm.raw[0]) | ((uint64_t)__builtin_amdgcn_readfirstlane(sm.raw[1]) << 32);
+                vw = (uint64_t)__builtin_amdgcn_readfirstlane(sm.raw[2]) | ((uint64_t)__builtin_amdgcn_readfirstlane(sm.raw[3]) << 32);
+                hd = __builtin_amdgcn_readfirstlane(sm.raw[4]);
             }
-            const uint32_t hd = sm.raw[fmt == 0 ? 0 : 4];
-            s.ppos = (uint8_t)(hd & 0xff); s.pwl = (uint8_t)((hd >> 8) & 0xff);
-            s.epos = (uint8_t)((hd >> 16) & 0xff); s.ewl = (uint8_t)(hd >> 24);
-            s.plies = 0; s.pad = 0;
-            int t = tid;
-            asm volatile("" : "+v"(t));   // opaque per iteration: keeps hipcc from hoisting (and then spilling) the
-                                          // per-tile masks / addresses out of the board loop
-            const int x = t / N, y = t % N;
-            sm.obits[t] = tile_open_bits<N>(s.hw, s.vw, t);
-            const bool slot_ok = (x < S) && (y < S);
-            const int slot = x * S + y;
-            f32x4 xa, xb;
-            xa[0] = (t == s.ppos) ? 1.f : 0.f;
-            xa[1] = (float)s.pwl;
-            xa[2] = (t == s.epos) ? 1.f : 0.f;
-            xa[3] = (float)s.ewl;
-            xb[0] = (slot_ok && ((s.hw >> slot) & 1)) ? 1.f : 0.f;
-            xb[1] = (slot_ok && ((s.vw >> slot) & 1)) ? 1.f : 0.f;
-            xb[2] = 0.f; xb[3] = 0.f;
-            *reinterpret_cast<f32x4*>(sm.X0 + t * FPAD) = xa;
-            *reinterpret_cast<f32x4*>(sm.X0 + t * FPAD + 4) = xb;
+            const Open op = make_open<N>(hw, vw);
+            auto open_word = [&](const BB& m, int w) -> uint32_t { return w == 0 ? (uint32_t)m.lo : w == 1 ? (uint32_t)(m.lo >> 32) : (uint32_t)m.hi; };
+            if (tid < V) {
+                int t = tid;
+                asm volatile("" : "+v"(t));   // opaque per iteration: nothing per-tile is hoisted out of the board loop
+                const int x = (t * 57) >> 9, y = t - 9 * x;                 // t / 9, t % 9 for t < 81
+                const int ppos = hd & 0xff, pwl = (hd >> 8) & 0xff, epos = (hd >> 16) & 0xff, ewl = hd >> 24;
+                const bool slot_ok = (x < S) && (y < S);
+                const int slot = (x * S + y) & 63;
+                u32x4 xr;                                                    // all six features are small integers: exact in fp16
+                xr[0] = cvt_pk_f16((t == ppos) ? 1.f : 0.f, (float)pwl);
+                xr[1] = cvt_pk_f16((t == epos) ? 1.f : 0.f, (float)ewl);
+                xr[2] = cvt_pk_f16((slot_ok && bit_of64(hw, slot)) ? 1.f : 0.f, (slot_ok && bit_of64(vw, slot)) ? 1.f : 0.f);
+                xr[3] = 0u;
+                *reinterpret_cast<u32x4*>(&sm.X0[t][0]) = xr;
+                const int w = t >> 5, sft = t & 31;
+                const uint32_t deg = 1u + ((open_word(op.U, w) >> sft) & 1u) + ((open_word(op.D, w) >> sft) & 1u) +
+                                     ((open_word(op.L, w) >> sft) & 1u) + ((open_word(op.R, w) >> sft) & 1u);
+                sm.dinv[t] = dinv_of((int)deg);
+            }
+#pragma unroll
+            for (int it = 0; it < (AF_BLOCKS + NWV - 1) / NWV; ++it) {
+                const int blk = wave + NWV * it;                             // wave-uniform
+                if (blk < AF_BLOCKS) {
+                    const int kb = (AF_KB_PACK >> (2 * blk)) & 3, nt = (AF_NT_PACK >> (3 * blk)) & 7;
+                    int n = 16 * nt + c;
+                    asm volatile("" : "+v"(n));
+                    u32x4 fr = (u32x4){0u, 0u, 0u, 0u};
+                    if (n < V) {
+                        const int w = nt >> 1, sft = n & 31;                 // n >> 5 == nt >> 1: the word is wave-uniform
+                        // window of row n of (A + I) around the diagonal: bit (k - n + 9), k = n-9 (U), n-1 (L), n, n+1 (R), n+9 (D)
+                        const uint32_t win = (1u << 9) | ((open_word(op.U, w) >> sft) & 1u) | (((open_word(op.L, w) >> sft) & 1u) << 8) |
+                                             (((open_word(op.R, w) >> sft) & 1u) << 10) | (((open_word(op.D, w) >> sft) & 1u) << 18);
+                        const int d0 = 32 * kb + 4 * q - n + 9;              // window bit of k-slot e = 0; e = 4 sits 16 higher
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int d = d0 + 16 * h;
+                            uint32_t nib = (d >= 0) ? (win >> min(d, 31)) : (win << min(-d, 4));
+                            nib &= 0xFu;
+                            const uint32_t t2 = nib | (nib << 15);           // b0 -> bit 0, b1 -> bit 16, b2 -> bit 2, b3 -> bit 18
+                            fr[2 * h] = (t2 & 0x00010001u) * 0x3C00u;        // fp16 1.0 = 0x3C00 in each selected half
+                            fr[2 * h + 1] = (t2 & 0x00040004u) * 0x0F00u;
+                        }
+                    }
+                    *reinterpret_cast<u32x4*>(&sm.AF[blk][lane][0]) = fr;
+                }
+            }
         }
         int bn = b + gridDim.x;
         while (bn < B && active && !active[bn]) bn += gridDim.x;
         __syncthreads();
         AQG_STAMP_AT(0)
-        uint32_t rawreg = 0;                                                // next board's record: one dword per lane,
-        if (bn < B && tid < ndw) rawreg = reinterpret_cast<const uint32_t*>(states)[(size_t)bn * ndw + tid];   // parked in LDS below
-        // ---- setup step 2 + layer 1a
-        if (tid < V) {
-            int t = tid;
-            asm volatile("" : "+v"(t));
-            const int ob = sm.obits[t];
-            const int tu = t >= 9 ? t - 9 : t, td = t < 72 ? t + 9 : t, tl = t > 0 ? t - 1 : t, tr = t < 80 ? t + 1 : t;
-            const float di = dinv_of_bits(ob);
-            f32x4 k4;
-            k4[0] = di * di;
-            k4[1] = (ob & 1) ? di * dinv_of_bits(sm.obits[tu]) : 0.f;
-            k4[2] = (ob & 2) ? di * dinv_of_bits(sm.obits[td]) : 0.f;
-            k4[3] = (ob & 4) ? di * dinv_of_bits(sm.obits[tl]) : 0.f;
-            const float kr = (ob & 8) ? di * dinv_of_bits(sm.obits[tr]) : 0.f;
-            *reinterpret_cast<f32x4*>(&sm.coef[prow(t)][0]) = k4;
-            sm.coef[prow(t)][4] = kr;
+        uint32_t rawreg = 0;                                                // next board's record: one dword per lane
+        if (bn < B && tid < ndw) rawreg = reinterpret_cast<const uint32_t*>(states)[(size_t)bn * ndw + tid];
+        f32x4 acc[6][JT], out[6][JT];
+        // ---- layer 1: Z = X0 W1 (one MFMA per tile), aggregation, planes
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f32x4 v = k4[0] * *reinterpret_cast<const f32x4*>(sm.X0 + t * FPAD + 4 * h) +
-                                k4[1] * *reinterpret_cast<const f32x4*>(sm.X0 + tu * FPAD + 4 * h) +
-                                k4[2] * *reinterpret_cast<const f32x4*>(sm.X0 + td * FPAD + 4 * h) +
-                                k4[3] * *reinterpret_cast<const f32x4*>(sm.X0 + tl * FPAD + 4 * h) +
-                                kr * *reinterpret_cast<const f32x4*>(sm.X0 + tr * FPAD + 4 * h);
-                *reinterpret_cast<f32x4*>(sm.AX + prow(t) * FPAD + 4 * h) = v;
-            }
+        for (int m = 0; m < 6; ++m) {
+            u32x4 xf = *reinterpret_cast<const u32x4*>(&sm.X0[16 * m + c][0]);
+            if (q >= 2) xf = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < JT; ++j) acc[m][j] = mfma_f16(xf, w1f[j], (f32x4){0.f, 0.f, 0.f, 0.f});
         }
+        AQG_STAMP_AT(8)
+        adj_matmul<JT>(sm, acc, lane, out);
+        AQG_STAMP_AT(9)
+        adj_store<JT, false>(sm, out, 0, wave, lane, nullptr);
+        AQG_STAMP_AT(10)
         __syncthreads();
         AQG_STAMP_AT(1)
-        // ---- layer 1b (f32 VALU, K = 6) -> split planes
-        {
-            const int cg = lane & 7, rs = lane >> 3;
-            const int colb = 32 * wave + 4 * cg;
-            // W1 for this lane's 4 columns as six 4-wide vectors (one per input feature): the K = 6 contraction is then
-            // six packed FMAs per row instead of 24 scalar ones
-            f32x4 wc[6];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(pk + PackedLayout::W1 + (colb + e) * FPAD);
-                const float2 hi = *reinterpret_cast<const float2*>(pk + PackedLayout::W1 + (colb + e) * FPAD + 4);
-                wc[0][e] = lo[0]; wc[1][e] = lo[1]; wc[2][e] = lo[2]; wc[3][e] = lo[3]; wc[4][e] = hi.x; wc[5][e] = hi.y;
-            }
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(pk + PackedLayout::B1 + colb);
-#pragma unroll
-            for (int it = 0; it < STRIPE_ITERS; ++it) {
-                const int r = stripe_row(it, rs);
-                if (r < V) {
-                    const f32x4 xa = *reinterpret_cast<const f32x4*>(sm.AX + prow(r) * FPAD);
-                    const float2 xb = *reinterpret_cast<const float2*>(sm.AX + prow(r) * FPAD + 4);
-                    f32x4 v = b1 + xa[0] * wc[0] + xa[1] * wc[1] + xa[2] * wc[2] + xa[3] * wc[3] + xb.x * wc[4] + xb.y * wc[5];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    store_split4<NPL, F16>(sm, r * PROW + 2 * colb, v);
-                }
-                if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();
-        AQG_STAMP_AT(2)
         // ---- layer 2
-        f32x4 acc[6][2];
-        AQG_DIAG_FENCE_AT(1);
-        stripe_matmul_bf16<NPL, F16>(sm, Bf, lane, acc);
-        AQG_DIAG_FENCE_AT(2);
+        stripe_matmul_mm<JT>(sm, Bf, lane, acc);
+        AQG_STAMP_AT(2)
+        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH3, wave, lane);             // lands under the aggregation
+        __builtin_amdgcn_sched_barrier(0);
+        AQG_STAMP_AT(11)
+        adj_matmul<JT>(sm, acc, lane, out);
+        AQG_STAMP_AT(12)
+        __syncthreads();                                                    // every wave is done reading the planes
+        AQG_STAMP_AT(13)
+        adj_store<JT, false>(sm, out, 1, wave, lane, nullptr);
+        AQG_STAMP_AT(14)
         __syncthreads();
         AQG_STAMP_AT(3)
-        load_bfrag<NPL>(Bf, pk + (F16 ? PackedLayout::WH3 : PackedLayout::WB3), wave, lane);            // lands under the layer-2 epilogue
-        __builtin_amdgcn_sched_barrier(0);
-        stripe_gather_bf16<NPL, F16, false>(sm, acc, bias2, wave, lane, nullptr);
-        AQG_DIAG_FENCE_AT(4);
-        __syncthreads();
-        AQG_STAMP_AT(4)
         // ---- layer 3 + mean pool
-        stripe_matmul_bf16<NPL, F16>(sm, Bf, lane, acc);
-        AQG_DIAG_FENCE_AT(8);
-        __syncthreads();
+        stripe_matmul_mm<JT>(sm, Bf, lane, acc);
+        AQG_STAMP_AT(4)
+        adj_matmul<JT>(sm, acc, lane, out);
+        AQG_STAMP_AT(15)
+        adj_store<JT, true>(sm, out, 2, wave, lane, pooled + (size_t)b * HID);
+        if (tid < ndw) sm.raw[tid] = rawreg;
+        __syncthreads();                                                    // AF / X0 / dinv / planes are free for the next board
         AQG_STAMP_AT(5)
-        stripe_gather_bf16<NPL, F16, true>(sm, acc, bias3, wave, lane, pooled + (size_t)b * HID);
-        if (tid < ndw) sm.raw[tid] = rawreg;                                // setup (its only reader) is long done
-        __syncthreads();
-        AQG_STAMP_AT(6)
 #ifdef AQG_STAMP
         ++st_n;
 #endif
@@ -929,8 +886,8 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_bf16_kernel(
 #ifdef AQG_STAMP
     if (blockIdx.x == 0 && tid == 0) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(pooled + (size_t)B * HID);
-        for (int i = 0; i < 8; ++i) o[i] = st_sum[i];
-        o[8] = (unsigned long long)st_n;
+        for (int i = 0; i < 16; ++i) o[i] = st_sum[i];
+        o[16] = (unsigned long long)st_n;
     }
 #endif
 }
@@ -1049,15 +1006,15 @@ __global__ __launch_bounds__(256) void gcn_heads_kernel(const float* __restrict_
 }
 
 // Trunk variants (aqg_set_option("trunk_variant", v)):
-//   0 exact f32 MFMA, weights resident, 1 workgroup/CU      1 exact f32 MFMA, 2 workgroups/CU
-//   3 fp16x3 split MFMA (hi+lo fp16 planes = 22 mantissa bits: fp32-equivalent), 2/CU  [default]
-//   4 bf16x3 split MFMA (~2^-16 relative per product), 2/CU
-// A bf16x6 (three bf16 planes) instantiation of the same template was the default for a while and is NOT shipped: its
-// 74.9 KB image puts the second-resident workgroup's third plane above 128 KB of the CU's LDS, where cross-wave
-// hand-offs through s_waitcnt lgkmcnt(0) + s_barrier were observed to read stale data on cold launches.
-// Measured and dropped this round (slower): 3 workgroups/CU under a 168-VGPR cap (spills), and an 8-wave /
-// 16-column-stripe form at 4 waves per SIMD (spills + doubled A-operand LDS reads): 15.6 M vs 23.3 M boards/s.
+//   0 exact f32-input MFMA + VALU gather, weights resident, 1 workgroup/CU      1 the same, 2 workgroups/CU
+//   3 all-MFMA fp16 split trunk, 8 waves per board (16-column stripes, 4 waves per SIMD)  [default]
+//   4 all-MFMA fp16 split trunk, 4 waves per board (32-column stripes, 2 waves per SIMD)
+// An earlier split-precision kernel kept the VALU gather of variants 0/1 on a 16-bit plane image (bf16 x6 / x3 and
+// fp16 x3 forms).  It was removed: its gather read plane bytes no wave had written for the current board (harmless
+// with benign leftovers, wrong once the LDS held NaN patterns -- tools/cold_launch_check.py poisons the LDS before
+// the first launch of a process to catch exactly this class of bug).
 int g_trunk_variant = 3;
+int g_trunk_phase_delay = 100;   // x 64 cycles: start offset of the second-resident workgroups (tools/phase_scan.py)
 int g_trunk_grid = 0;      // 0 = default persistent grid; otherwise override (diagnostics)
 
 // Diagnostic: fill every CU's LDS with NaN bit patterns so that any read-before-write in a later kernel shows up
@@ -1125,14 +1082,14 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     } else if (g_trunk_variant == 1) {
         int grid = B < 512 ? B : 512;
         hipLaunchKernelGGL((gcn_trunk_boards_kernel<false, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
-    } else if (g_trunk_variant == 3) {
+    } else if (g_trunk_variant == 4) {
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_bf16_kernel<3, 2, true>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
+        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, g_trunk_phase_delay);
     } else {
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_bf16_kernel<3, 2, false>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
+        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, g_trunk_phase_delay);
     }
     if (g_profile_trunk) hipEventRecord(prof_event(), st);
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;

@@ -34,7 +34,8 @@ FWD_FLOP_PER_BOARD = 5492480                                         # SURVEY 8(
 HBM_BYTES_PER_BOARD = 169760                                         # layer-granular algorithmic bytes
 PEAK_F32_MFMA = 157.3e12                                             # MI355X_MICROARCH.md: f32-input MFMA
 PEAK_F16_MFMA = 2500.0e12                                            # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
-SPLIT_TERMS = 3                                                      # f16x3: hi*hi + hi*lo + lo*hi per f32 product
+SPLIT_TERMS = 3                                                      # hi*hi + hi*lo + lo*hi per f32 product
+TRUNK_MFMA_PER_BOARD = 4 * (12 + 2 * 144 + 3 * 40)                   # 16x16x32 fp16 MFMAs issued per board (incl. aggregation, padding)
 PEAK_HBM = 8.0e12
 # HBM bytes per board actually moved by the default trunk, from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
 # WRITE_SIZE, separate passes; profiles/r01_trunk_bf16x6_hbm_pmc.csv, B = 65,536 boards per launch).  PMC counters
@@ -156,7 +157,7 @@ def main():
                                               _lib.ptr(value), _lib.stream_ptr(dev)), "fwd")
     fwd_ms = time_ms(fwd, 200, warmup=20)
     variants = {}
-    for name, v in (("f32_mfma_exact", 1), ("f16x3_split", 3), ("bf16x3_split", 4)):
+    for name, v in (("f32_mfma_exact", 1), ("f16_split_mm_8wave", 3), ("f16_split_mm_4wave", 4)):
         _lib.set_option("trunk_variant", v)
         ms = time_ms(fwd, 100, warmup=10)
         variants[name] = {"boards_per_s": B / (ms * 1e-3), "ms": ms}
@@ -203,11 +204,11 @@ def main():
                             "boards_per_s": B / (fwd_ms * 1e-3), "ms": fwd_ms, "trunk_variants": variants,
                             "mfma_frac": B / (fwd_ms * 1e-3) * FWD_FLOP_PER_BOARD / PEAK_F32_MFMA,
                             "hbm_frac_survey_formula": B / (fwd_ms * 1e-3) * HBM_BYTES_PER_BOARD / PEAK_HBM},
-            "roofline": {"kernel": "gcn_trunk_boards_bf16_kernel<3,2,true> (GCN trunk, fp16 two-plane split MFMA)", "bound": "mfma",
+            "roofline": {"kernel": "gcn_trunk_boards_mm_kernel<1,2> (GCN trunk: linear maps + aggregation on fp16 split MFMA)", "bound": "mfma",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / SPLIT_TERMS / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / (PEAK_F16_MFMA / SPLIT_TERMS),
                          "traffic": TRUNK_HBM_BYTES_PER_BOARD_PMC * leaf_evals / max(trunk_launches, 1),
-                         "traffic_note": "HBM bytes per launch = 3,827 B/board (rocprofv3 PMC on the three-plane build of this kernel, "
+                         "traffic_note": "HBM bytes per launch = 3,827 B/board (rocprofv3 PMC on an earlier build with the same weight-streaming pattern, "
                                          "profiles/r01_trunk_bf16x6_hbm_pmc.csv; dominated by the L2-missing share of the per-board weight "
                                          "fragment reads) x boards per launch; algorithmic layer-granular figure is 169,760 B/board "
                                          "(hbm_frac_survey_formula): activations never leave LDS",
@@ -216,9 +217,10 @@ def main():
                          "flop_per_board": TRUNK_FLOP_PER_BOARD,
                          "hbm_frac_survey_formula": boards_per_s_kernel * HBM_BYTES_PER_BOARD / PEAK_HBM,
                          "frac_vs_f32_input_mfma_peak": achieved / PEAK_F32_MFMA,
-                         "f16_mfma_issued_tflops": achieved * SPLIT_TERMS * (96.0 / 81.0) / 1e12, "f16_mfma_peak_tflops": PEAK_F16_MFMA / 1e12,
-                         "note": "default trunk = fp16 two-plane split MFMA (f32 data, f32 accumulate, 3 fp16 products hi*hi+hi*lo+lo*hi "
-                                 "per f32 product: fp32-equivalent, same 1e-5/1e-4 tolerance as the exact f32-input MFMA variant). "
+                         "f16_mfma_issued_tflops": boards_per_s_kernel * TRUNK_MFMA_PER_BOARD * 16384 / 1e12, "f16_mfma_peak_tflops": PEAK_F16_MFMA / 1e12,
+                         "note": "default trunk = all-MFMA fp16 split (f32 data, f32 accumulate, 3 fp16 products hi*hi+hi*lo+lo*hi per f32 "
+                                 "product; the GCN aggregation is a banded 0/1 adjacency MFMA: fp32-equivalent, same 1e-5/1e-4 tolerance as "
+                                 "the exact f32-input MFMA variant). "
                                  "achieved = ALGORITHMIC f32 FLOP/s (5,432,832 per board x boards / kernel time from HIP events around "
                                  "every launch); peak = dense fp16 MFMA peak / 3 split terms = the matrix-pipe roof of this algorithm "
                                  "(the exact f32-input MFMA roof of SURVEY 8d is 157.3 TFLOP/s: frac_vs_f32_input_mfma_peak). Launches "

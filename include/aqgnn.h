@@ -33,8 +33,9 @@ extern "C" {
 
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
-/* tuning knobs: "trunk_variant" 0/1 = exact f32-input MFMA with 1/2 workgroups per CU, 3 = fp16 two-plane split MFMA
- * (hi*hi + hi*lo + lo*hi: fp32-equivalent products, default), 4 = bf16 two-plane split MFMA (~2^-16 per product); "profile_trunk" 0/1 = event pairs around trunk launches */
+/* tuning knobs: "trunk_variant" 0/1 = exact f32-input MFMA with 1/2 workgroups per CU, 3 = all-MFMA fp16 split trunk
+ * (hi*hi + hi*lo + lo*hi: fp32-equivalent products; 8 waves per board, default), 4 = the same with 4 waves per board;
+ * "trunk_phase_delay" = start offset of the second-resident workgroups in units of 64 cycles; "profile_trunk" 0/1 = event pairs around trunk launches */
 int aqg_set_option(const char* name, int value);
 /* Measurement aid (bench.py): with option "profile_trunk" = 1 a HIP event pair is recorded around every launch of the
  * dominant kernel (the GCN trunk) on its launch stream.  This call waits for the last recorded event, accumulates
@@ -74,6 +75,9 @@ int aqg_state_status(int board_size, const uint8_t* states72, int B, int plies_f
  *   HW1T[H][H]   hidden layer of both heads, [k][unit]: unit<H/2 policy_head.0, else value_head.0    hb1 [H]
  *   PW2T[H/2][256] policy_head.2.weight transposed ([k][a], a padded to 256)   pb2 [256]
  *   VW2 [H/2]    value_head.2.weight                                vb2 [1] (+3 pad)
+ *   WF2, WF3     W2^T / W3^T again in f32 MFMA B-fragment order (exact-f32 trunk variants 0/1)
+ *   WH2, WH3     fp16 hi/lo planes of W2^T / W3^T in 16x16x32 MFMA B-fragment order (default trunk)
+ *   WH1          fp16 hi/lo of gcn_layers.0.lin.weight folded into one 32-deep k block (default trunk, layer 1)
  * aqg_gcn_packed_floats() returns the total; aqg_gcn_pack_weights_host() fills a HOST buffer from the 14
  * state_dict tensors given as HOST float32 pointers in the key order of KEYS in INTEGRATION.md. */
 size_t aqg_gcn_packed_floats(int board_size);

@@ -139,7 +139,7 @@ def test_gnn_forward_boards_vs_fp64_oracle(dev, variant):
     _lib.set_option("trunk_variant", 3)
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [1, 3, 4])
 def test_gnn_forward_scaled_weights(dev, variant):
     """Weights scaled up so activations are O(10): relative tolerance still holds (catches layout slips that
     small random weights could hide)."""

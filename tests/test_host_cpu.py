@@ -103,25 +103,15 @@ def test_weight_packing_layout():
     off = 128 * 8 + 128
     W2T = out[off:off + 128 * 128].reshape(128, 128)
     assert np.array_equal(W2T, p["gcn_layers.1.lin.weight"].T)
-    WF2, WB2 = 67396, 100164                                               # offsets documented in include/aqgnn.h / gcn_forward.hip
-    WH2 = WB2 + 2 * 3 * 128 * 128 // 2
-    assert n == WH2 + 2 * 2 * 128 * 128 // 2
+    WF2 = 67396                                                            # offsets documented in include/aqgnn.h / gcn_forward.hip
+    WH2 = WF2 + 2 * 128 * 128
+    WH1 = WH2 + 2 * 2 * 128 * 128 // 2
+    assert n == WH1 + 4 * 2 * 64 * 4
     wf2 = out[WF2:WF2 + 128 * 128].reshape(4, 2, 8, 64, 4)                 # [wave][ntile][s4][lane][i]
     for (w, j, s4, lane, i) in [(0, 0, 0, 0, 0), (3, 1, 7, 63, 3), (2, 0, 5, 17, 2), (1, 1, 2, 40, 1)]:
         c, q = lane & 15, lane >> 4
         k = (q & 1) * 64 + (q >> 1) * 32 + 4 * s4 + i
         assert wf2[w, j, s4, lane, i] == p["gcn_layers.1.lin.weight"][32 * w + 16 * j + c, k]
-    # bf16 3-way split fragments: hi + mid + lo reproduces the f32 weight to ~2^-24 relative
-    wb2 = out[WB2:WB2 + 3 * 128 * 128 // 2].view(np.uint32).reshape(3, 4, 2, 4, 64, 4)   # [plane][wave][ntile][kb][lane][dword]
-    def bf(u16):
-        return (np.uint32(u16) << np.uint32(16)).view(np.float32)
-    for (w, j, kb, lane, d) in [(0, 0, 0, 0, 0), (3, 1, 3, 63, 3), (1, 0, 2, 21, 1)]:
-        c, q = lane & 15, lane >> 4
-        nn, k = 32 * w + 16 * j + c, 32 * kb + 8 * q + 2 * d
-        for half, kk in ((0, k), (1, k + 1)):
-            parts = [bf((int(wb2[pl, w, j, kb, lane, d]) >> (16 * half)) & 0xFFFF) for pl in range(3)]
-            ref = p["gcn_layers.1.lin.weight"][nn, kk]
-            assert abs(float(parts[0]) + float(parts[1]) + float(parts[2]) - float(ref)) <= 2.0 ** -22 * abs(float(ref)) + 1e-30
     # fp16 2-way split fragments (default trunk): hi = RNE_f16(w), lo = RNE_f16(w - hi)
     for L, key in ((0, "gcn_layers.1.lin.weight"), (1, "gcn_layers.2.lin.weight")):
         wh = out[WH2 + L * 128 * 128:WH2 + (L + 1) * 128 * 128].view(np.uint16).reshape(2, 4, 2, 4, 64, 8)   # [plane][wave][ntile][kb][lane][8 halves]
@@ -133,6 +123,14 @@ def test_weight_packing_layout():
         assert np.array_equal(wh[0], hi[nn, kk].view(np.uint16)) and np.array_equal(wh[1], lo[nn, kk].view(np.uint16))
         rec = hi.astype(np.float64) + lo.astype(np.float64)
         assert np.max(np.abs(rec - W)) <= 2.0 ** -22 * np.max(np.abs(W))
+    # layer-1 fragments: k-slots 0..7 = hi(W1[n][0..5]),0,0   8..15 = lo(...),0,0   16..31 = 0
+    w1 = out[WH1:WH1 + 4 * 2 * 64 * 4].view(np.uint16).reshape(4, 2, 4, 16, 8)                        # [wave][ntile][q][c][8 halves]
+    W = p["gcn_layers.0.lin.weight"].astype(np.float32)                                               # [128, 6]
+    hi = W.astype(np.float16)
+    lo = (W - hi.astype(np.float32)).astype(np.float16)
+    cols = (32 * np.arange(4)[:, None, None] + 16 * np.arange(2)[None, :, None] + np.arange(16)[None, None, :])   # [wave][ntile][c]
+    assert np.array_equal(w1[:, :, 0, :, :6], hi[cols].view(np.uint16)) and np.array_equal(w1[:, :, 1, :, :6], lo[cols].view(np.uint16))
+    assert not w1[:, :, :2, :, 6:].any() and not w1[:, :, 2:].any()
 
 
 _GLOO_WORKER = r'''

@@ -33,6 +33,7 @@ def child(variant):
     m = m.to("cuda").eval()
     pk = m.packed_weights(dev)
     st = torch.from_numpy(recs).to(dev)
+    _lib.poison_lds(dev)
     outs = []
     for _ in range(40):
         pooled = torch.full((B, 128), float("nan"), device=dev)
