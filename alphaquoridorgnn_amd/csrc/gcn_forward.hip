@@ -1014,7 +1014,8 @@ __global__ __launch_bounds__(256) void gcn_heads_kernel(const float* __restrict_
 // with benign leftovers, wrong once the LDS held NaN patterns -- tools/cold_launch_check.py poisons the LDS before
 // the first launch of a process to catch exactly this class of bug).
 int g_trunk_variant = 3;
-int g_trunk_phase_delay = 100;   // x 64 cycles: start offset of the second-resident workgroups (tools/phase_scan.py)
+int g_trunk_phase_delay = 100;   // x 64 cycles: start offset of the second-resident workgroups, applied to launches of
+                                 // >= 8192 boards (+4-11 % there; a wash at the ~2,000-board launches of the MCTS; tools/phase_scan.py)
 int g_trunk_grid = 0;      // 0 = default persistent grid; otherwise override (diagnostics)
 
 // Diagnostic: fill every CU's LDS with NaN bit patterns so that any read-before-write in a later kernel shows up
@@ -1050,9 +1051,10 @@ static hipEvent_t prof_event() {
 
 int profile_collect(double* total_ms, long long* launches, long long* boards, int reset) {
     if (g_prof_used) {
-        if (hipEventSynchronize(g_prof_events[g_prof_used - 1]) != hipSuccess) return fail("hipEventSynchronize");
         for (size_t i = 0; i + 1 < g_prof_used; i += 2) {
             float ms = 0.f;
+            // launches may sit on several streams (engine.MultiSetSelfPlay): wait for every pair, not just the last one
+            if (hipEventSynchronize(g_prof_events[i + 1]) != hipSuccess) return fail("hipEventSynchronize");
             if (hipEventElapsedTime(&ms, g_prof_events[i], g_prof_events[i + 1]) != hipSuccess) return fail("hipEventElapsedTime");
             g_prof_ms += ms;
             ++g_prof_launches;
@@ -1085,11 +1087,11 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     } else if (g_trunk_variant == 4) {
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, g_trunk_phase_delay);
+        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, B >= 8192 ? g_trunk_phase_delay : 0);
     } else {
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, g_trunk_phase_delay);
+        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, B >= 8192 ? g_trunk_phase_delay : 0);
     }
     if (g_profile_trunk) hipEventRecord(prof_event(), st);
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;

@@ -15,6 +15,8 @@
 // every game has exactly one leaf in flight, so no virtual loss is needed and per-game semantics equal the
 // sequential reference.
 #include "aqg_common.hpp"
+#include <vector>
+#include <cstring>
 #include "legal_wave.hpp"
 #include "../../include/aqgnn.h"
 
@@ -28,6 +30,8 @@ int launch_legal_actions(int N, const void* states, int fmt, int B, uint8_t* mas
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
                               hipStream_t st);
+extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_profile_trunk;
+int g_use_graph = 1;       // aqg_set_option("use_graph", 0) forces plain launches
 
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
@@ -450,7 +454,7 @@ static int validate(const aqg_engine& e) {
 }
 
 template <int N>
-static int run_sims(const aqg_engine& e, hipStream_t st) {
+static int enqueue_sims(const aqg_engine& e, hipStream_t st) {
     const dim3 grid((e.num_games + 3) / 4), block(256);
     hipLaunchKernelGGL(engine_begin_move_kernel, dim3((e.num_games + 255) / 256), dim3(256), 0, st, e);
     for (int sim = 0; sim < e.sims; ++sim) {
@@ -465,6 +469,50 @@ static int run_sims(const aqg_engine& e, hipStream_t st) {
     }
     hipLaunchKernelGGL(engine_step_kernel<N>, grid, block, 0, st, e, 1, 0);   // expand + backup of the last simulation
     return check_launch("engine simulation kernels");
+}
+
+// One move's search is 3 * sims + 2 launches with constant arguments: on a capturable (non-default) stream it is
+// captured once into a hipGraph and replayed per move, so the host cost per move is one graph launch instead of ~600
+// kernel launches (with several game sets on several streams the host is otherwise the bottleneck).  The cache key is
+// the engine struct itself plus the trunk options the launches read.
+struct SimGraph {
+    aqg_engine e;
+    int opts[4];
+    hipGraphExec_t exec;
+};
+static std::vector<SimGraph> g_sim_graphs;
+
+template <int N>
+static int run_sims(const aqg_engine& e, hipStream_t st) {
+    if (!g_use_graph || g_profile_trunk || st == nullptr || e.sims < 4) return enqueue_sims<N>(e, st);
+    const int opts[4] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, N};
+    for (const SimGraph& g : g_sim_graphs)
+        if (!memcmp(&g.e, &e, sizeof(aqg_engine)) && !memcmp(g.opts, opts, sizeof(opts))) {
+            if (hipGraphLaunch(g.exec, st) != hipSuccess) return fail("hipGraphLaunch");
+            return 0;
+        }
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return enqueue_sims<N>(e, st);                       // stream not capturable: plain launches
+    }
+    const int r = enqueue_sims<N>(e, st);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(st, &graph);
+    if (r) { if (graph) (void)hipGraphDestroy(graph); return r; }
+    if (ec != hipSuccess || !graph) return fail("hipStreamEndCapture");
+    SimGraph g;
+    memcpy(&g.e, &e, sizeof(aqg_engine));
+    memcpy(g.opts, opts, sizeof(opts));
+    const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) return fail("hipGraphInstantiate");
+    if (g_sim_graphs.size() >= 16) {                         // small FIFO cache: engines come and go
+        (void)hipGraphExecDestroy(g_sim_graphs.front().exec);
+        g_sim_graphs.erase(g_sim_graphs.begin());
+    }
+    g_sim_graphs.push_back(g);
+    if (hipGraphLaunch(g.exec, st) != hipSuccess) return fail("hipGraphLaunch");
+    return 0;
 }
 
 template <int N>

@@ -164,6 +164,88 @@ class BatchedSelfPlay:
         return out
 
 
+class MultiSetSelfPlay:
+    """K independent BatchedSelfPlay sets of a rank's games, each on its own HIP stream.
+
+    One set is a strictly serial chain per simulation (step -> trunk -> heads): while its latency-bound step / heads
+    kernels run, most of the chip idles, and the trunk's last boards leave CUs empty.  Games are independent, so
+    splitting them into K sets whose move() calls are enqueued round-robin on K streams lets the GPU fill those holes
+    with another set's kernels (+9 % games/s at K = 2 or 3 on top of the hipGraph replay; K >= 4 is SLOWER: with the
+    default stream that is more streams than the runtime's 4 hardware queues, and streams sharing a queue serialise).  Set k is
+    bit-identical to a stand-alone BatchedSelfPlay(num_games_k, seed = seed * 64 + k): nothing is shared but the
+    read-only packed weights."""
+
+    def __init__(self, model=None, num_games=2048, sims=50, num_sets=2, seed=0, device=None, **kw):
+        self.dev = _lib.require_gpu(device)
+        k = max(1, min(int(num_sets), int(num_games)))
+        sizes = [num_games // k + (1 if i < num_games % k else 0) for i in range(k)]
+        self.streams = [torch.cuda.Stream(device=self.dev) for _ in sizes]
+        self.sets = []
+        ready = torch.cuda.current_stream(self.dev).record_event()   # e.g. the model's weight upload on the caller's stream
+        for i, g in enumerate(sizes):
+            with torch.cuda.stream(self.streams[i]):
+                self.streams[i].wait_event(ready)
+                self.sets.append(BatchedSelfPlay(model, num_games=g, sims=sims, seed=int(seed) * 64 + i, device=self.dev, **kw))
+        self.G, self.sims = int(num_games), int(sims)
+        self.max_plies = self.sets[0].max_plies
+        self.A, self.N = self.sets[0].A, self.sets[0].N
+        self._live = [True] * k
+        self.sync()
+
+    def _each(self, live_only=False):
+        for i, (st, eng) in enumerate(zip(self.streams, self.sets)):
+            if live_only and not self._live[i]:
+                continue
+            with torch.cuda.stream(st):
+                yield i, eng
+
+    def sync(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def reset(self):
+        for _, eng in self._each():
+            eng.reset()
+        self._live = [True] * len(self.sets)
+
+    def move(self):
+        """One move for every active game of every live set (a set whose games have all ended is skipped)."""
+        for _, eng in self._each(live_only=True):
+            eng.move()
+
+    def counters(self):
+        tot = dict(active=0, finished=0, dead_ends=0, leaf_evals=0, terminal_sims=0)
+        for i, eng in self._each():
+            c = eng.counters()                    # .cpu() inside synchronises this set's stream only
+            self._live[i] = self._live[i] and c["active"] > 0
+            for key in tot:
+                tot[key] += c[key]
+        return tot
+
+    def play_generation(self, check_every=4):
+        ply = 0
+        while True:
+            self.move()
+            ply += 1
+            if ply >= self.max_plies or ply % check_every == 0:
+                if self.counters()["active"] == 0 or ply >= self.max_plies:
+                    break
+        return self.counters()
+
+    def history_tensors(self):
+        parts = []
+        for _, eng in self._each():
+            parts.append(eng.history_tensors())
+        self.sync()
+        cur = torch.cuda.current_stream(self.dev)
+        for st in self.streams:
+            cur.wait_stream(st)
+        for p in parts:
+            for x in p:
+                x.record_stream(cur)              # the caching allocator must not recycle them under the concatenation
+        return tuple(torch.cat([p[j] for p in parts], 0) for j in range(3))
+
+
 def gather_history(states72, visits, z, group=None):
     """The one exchange step per generation: all-gather the ragged (s, pi, z) tuples of every rank.
     Counts are gathered first, payloads are padded to the max count (RCCL needs equal sizes) and trimmed after.

@@ -14,7 +14,7 @@ import torch
 
 from . import pv_mcts
 from .constants import PV_NETWORK_PATH, BOARD_SIZE
-from .engine import BatchedSelfPlay, gather_history
+from .engine import BatchedSelfPlay, MultiSetSelfPlay, gather_history
 from .pv_network_gnn import GNNNetwork, POLICY_OUTPUT_SIZE
 
 SP_GAME_COUNT = 50    # Number of games for self-play (self_play.py:19; 25000 in the original version)
@@ -72,8 +72,9 @@ def self_play(model=None, games=None):
     vis = torch.zeros((0, POLICY_OUTPUT_SIZE), dtype=torch.int16, device='cuda')
     z = torch.zeros((0,), dtype=torch.int8, device='cuda')
     if mine > 0:
-        eng = BatchedSelfPlay(model, num_games=mine, sims=pv_mcts.PV_EVALUATE_COUNT, board_size=BOARD_SIZE,
-                              temperature=SP_TEMPERATURE, seed=1234 + rank)
+        # >= 256 games: two independent game sets on two streams fill the holes of each other's serial kernel chains
+        eng = MultiSetSelfPlay(model, num_games=mine, sims=pv_mcts.PV_EVALUATE_COUNT, num_sets=2 if mine >= 256 else 1,
+                               board_size=BOARD_SIZE, temperature=SP_TEMPERATURE, seed=1234 + rank)
         c = eng.play_generation()
         print(f'\rSelf-play (rank {rank}: {c["finished"]}/{mine} games)', end='')
         st, vis, z = eng.history_tensors()

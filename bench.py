@@ -72,7 +72,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--games", type=int, default=2048, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=200, help="MCTS simulations per move")
+    ap.add_argument("--sets", type=int, default=2, help="independent game sets per GPU, one HIP stream each (engine.MultiSetSelfPlay)")
     ap.add_argument("--gnn-batch", type=int, default=4096)
+    ap.add_argument("--trunk-grid", type=int, default=0, help="developer knob: cap the trunk's persistent grid (0 = default 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--large-games", type=int, default=16384,
                     help="extra single-GPU leg: one generation at this many concurrent games (north star: >= 10k); 0 = skip")
@@ -89,27 +91,43 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from alphaquoridorgnn_amd import _lib
-    from alphaquoridorgnn_amd.engine import BatchedSelfPlay, gather_history
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay, MultiSetSelfPlay, gather_history
     from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
     lib = _lib.load()                    # no HIP library -> hard failure, there is no fallback path
 
+    if args.trunk_grid:
+        _lib.set_option("trunk_grid", args.trunk_grid)
     torch.manual_seed(0)                 # random-init weights of the reference architecture (synthetic; no checkpoints)
     model = GNNNetwork().to(dev).eval()
-    eng = BatchedSelfPlay(model, num_games=args.games, sims=args.sims, seed=1000 + rank)
+    eng = MultiSetSelfPlay(model, num_games=args.games, sims=args.sims, num_sets=args.sets, seed=1000 + rank)
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    sampled_boards = torch.zeros((len(eng.sets),), dtype=torch.int64, device=dev)
+    PROFILE_EVERY = 8      # plies whose trunk launches carry HIP event pairs (those plies use plain launches, the others
+                           # replay the captured hipGraph of a move, which cannot carry per-kernel events)
+
     def one_step(profile):
         eng.reset()
         ply = 0
         while True:
+            sampled = profile and ply % PROFILE_EVERY == 0
+            if sampled:                               # boards evaluated by the sampled launches: device-side sums on each
+                for i, e in eng._each():              # set's own stream, no host synchronisation
+                    sampled_boards[i] -= e.t["stat_leaf_evals"].sum()
+                _lib.set_option("profile_trunk", 1)
             eng.move()
+            if sampled:
+                _lib.set_option("profile_trunk", 0)
+                for i, e in eng._each():
+                    sampled_boards[i] += e.t["stat_leaf_evals"].sum()
             ply += 1
             if ply % 4 == 0 or ply >= eng.max_plies:
                 if profile:
+                    eng.sync()                        # events of every set's stream are complete before they are read
                     _lib.profile_collect()
                 if eng.counters()["active"] == 0 or ply >= eng.max_plies:
                     break
@@ -119,7 +137,6 @@ def main():
 
     for _ in range(args.warmup):
         one_step(False)
-    _lib.set_option("profile_trunk", 1)
     _lib.profile_collect(reset=True)
     sync_all()
     t0 = time.time()
@@ -132,7 +149,7 @@ def main():
     sync_all()
     elapsed = time.time() - t0
     trunk_ms, trunk_launches, trunk_rows = _lib.profile_collect(reset=True)
-    _lib.set_option("profile_trunk", 0)
+    trunk_boards = int(sampled_boards.sum().item())    # boards evaluated inside the event-bracketed launches
 
     tt = torch.tensor([elapsed, float(games), float(leaf_evals)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -167,7 +184,7 @@ def main():
     if world == 1 and args.large_games > 0:
         del eng
         torch.cuda.empty_cache()
-        eng = BatchedSelfPlay(model, num_games=args.large_games, sims=args.sims, seed=77)
+        eng = MultiSetSelfPlay(model, num_games=args.large_games, sims=args.sims, num_sets=args.sets, seed=77)
         torch.cuda.synchronize()
         t1 = time.time()
         c, _ = one_step(False)
@@ -177,8 +194,8 @@ def main():
                  "games_per_s": c["finished"] / dt, "s_per_generation": dt, "leaf_evals_per_s": c["leaf_evals"] / dt}
 
     if rank == 0:
-        achieved = leaf_evals * TRUNK_FLOP_PER_BOARD / (trunk_ms * 1e-3) if trunk_ms > 0 else 0.0   # rank 0's launches
-        boards_per_s_kernel = leaf_evals / (trunk_ms * 1e-3) if trunk_ms > 0 else 0.0
+        achieved = trunk_boards * TRUNK_FLOP_PER_BOARD / (trunk_ms * 1e-3) if trunk_ms > 0 else 0.0   # rank 0's sampled launches
+        boards_per_s_kernel = trunk_boards / (trunk_ms * 1e-3) if trunk_ms > 0 else 0.0
         out = {
             "metric": "self-play games/sec, 9x9 Quoridor (PV-MCTS, GNN evaluator), whole job",
             "value": total_games / elapsed,
@@ -194,7 +211,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]/[3]: one self-play generation per step -- concurrent 9x9 games per GPU "
                                    "played to termination, lock-step PV-MCTS, random-weight GNN evaluator, then the all-gather of (s,pi,z)",
-                       "games_per_gpu": args.games, "sims_per_move": args.sims, "board": "9x9", "walls": 10, "plies_for_draw": 116,
+                       "games_per_gpu": args.games, "game_sets_per_gpu": args.sets, "sims_per_move": args.sims, "board": "9x9", "walls": 10, "plies_for_draw": 116,
                        "temperature": 1.0, "c_puct": 1.25, "parallelism": f"games sharded over {world} rank(s), 1 all-gather per generation"},
             "leaf_evals_per_s": total_evals / elapsed,
             "sims_per_s": total_evals / elapsed,   # terminal simulations excluded
@@ -207,13 +224,14 @@ def main():
             "roofline": {"kernel": "gcn_trunk_boards_mm_kernel<1,2> (GCN trunk: linear maps + aggregation on fp16 split MFMA)", "bound": "mfma",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / SPLIT_TERMS / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / (PEAK_F16_MFMA / SPLIT_TERMS),
-                         "traffic": TRUNK_HBM_BYTES_PER_BOARD_PMC * leaf_evals / max(trunk_launches, 1),
+                         "traffic": TRUNK_HBM_BYTES_PER_BOARD_PMC * trunk_boards / max(trunk_launches, 1),
                          "traffic_note": "HBM bytes per launch = 3,827 B/board (rocprofv3 PMC on an earlier build with the same weight-streaming pattern, "
                                          "profiles/r01_trunk_bf16x6_hbm_pmc.csv; dominated by the L2-missing share of the per-board weight "
                                          "fragment reads) x boards per launch; algorithmic layer-granular figure is 169,760 B/board "
                                          "(hbm_frac_survey_formula): activations never leave LDS",
                          "launches": trunk_launches, "avg_launch_us": trunk_ms / max(trunk_launches, 1) * 1e3,
-                         "boards_per_launch_avg": leaf_evals / max(trunk_launches, 1),
+                         "boards_per_launch_avg": trunk_boards / max(trunk_launches, 1),
+                         "launches_sampled": "every trunk launch of every 8th ply of the timed region (those plies use plain launches; the rest replay a captured hipGraph)",
                          "flop_per_board": TRUNK_FLOP_PER_BOARD,
                          "hbm_frac_survey_formula": boards_per_s_kernel * HBM_BYTES_PER_BOARD / PEAK_HBM,
                          "frac_vs_f32_input_mfma_peak": achieved / PEAK_F32_MFMA,

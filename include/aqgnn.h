@@ -35,7 +35,8 @@ int aqg_abi_version(void);
 const char* aqg_last_error(void);
 /* tuning knobs: "trunk_variant" 0/1 = exact f32-input MFMA with 1/2 workgroups per CU, 3 = all-MFMA fp16 split trunk
  * (hi*hi + hi*lo + lo*hi: fp32-equivalent products; 8 waves per board, default), 4 = the same with 4 waves per board;
- * "trunk_phase_delay" = start offset of the second-resident workgroups in units of 64 cycles; "profile_trunk" 0/1 = event pairs around trunk launches */
+ * "trunk_phase_delay" = start offset of the second-resident workgroups in units of 64 cycles; "use_graph" 0/1 = replay
+ * a move's 3*sims+2 launches as one captured hipGraph when the stream is capturable (default 1); "profile_trunk" 0/1 = event pairs around trunk launches */
 int aqg_set_option(const char* name, int value);
 /* Measurement aid (bench.py): with option "profile_trunk" = 1 a HIP event pair is recorded around every launch of the
  * dominant kernel (the GCN trunk) on its launch stream.  This call waits for the last recorded event, accumulates

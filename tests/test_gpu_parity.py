@@ -303,6 +303,26 @@ def test_selfplay_generation_with_gnn(dev):
         off += p
 
 
+def test_multiset_selfplay_equals_standalone_sets(dev):
+    """engine.MultiSetSelfPlay (K game sets on K streams) = K stand-alone BatchedSelfPlay runs, bit for bit:
+    the sets share nothing but read-only weights, so concurrency must not change a single recorded tuple."""
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay, MultiSetSelfPlay
+    model, _ = _model(0)
+    multi = MultiSetSelfPlay(model, num_games=70, sims=10, num_sets=3, seed=9, board_size=9)
+    c = multi.play_generation()
+    assert c["active"] == 0 and c["finished"] == 70
+    st, vis, z = (x.cpu().numpy() for x in multi.history_tensors())
+    assert [e.G for e in multi.sets] == [24, 23, 23]
+    parts = []
+    for k, g in enumerate((24, 23, 23)):
+        eng = BatchedSelfPlay(model, num_games=g, sims=10, seed=9 * 64 + k, board_size=9)
+        eng.play_generation()
+        parts.append(tuple(x.cpu().numpy() for x in eng.history_tensors()))
+    assert np.array_equal(st, np.concatenate([p[0] for p in parts]))
+    assert np.array_equal(vis, np.concatenate([p[1] for p in parts]))
+    assert np.array_equal(z, np.concatenate([p[2] for p in parts]))
+
+
 # ------------------------------------------------------------------ drop-in surface (reference-shaped calls)
 def test_dropin_surface_play_and_policy(dev, tmp_path, monkeypatch):
     """The reference's call surface end to end on the GPU: pv_mcts_policy / pv_mcts_action on a State, self_play.play()
