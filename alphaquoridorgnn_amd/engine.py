@@ -9,6 +9,7 @@ Sharding: games are independent, so rank r of W simply owns its own 
 uniform stream; `gather_history` is the single exchange step per generation (all-gather over RCCL/xGMI).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -170,13 +171,17 @@ class MultiSetSelfPlay:
     One set is a strictly serial chain per simulation (step -> trunk -> heads): while its latency-bound step / heads
     kernels run, most of the chip idles, and the trunk's last boards leave CUs empty.  Games are independent, so
     splitting them into K sets whose move() calls are enqueued round-robin on K streams lets the GPU fill those holes
-    with another set's kernels (+9 % games/s at K = 2 or 3 on top of the hipGraph replay; K >= 4 is SLOWER: with the
-    default stream that is more streams than the runtime's 4 hardware queues, and streams sharing a queue serialise).  Set k is
+    with another set's kernels: 988 -> 1,082 games/s at K = 2 and 1,217 at K = 4 (2048 games x 200 sims, hipGraph replay
+    on).  K = 4 needs GPU_MAX_HW_QUEUES >= 5 (set to 8 by the package unless the user chose a value): with the runtime's
+    default of 4 hardware queues two of the streams share a queue, serialise, and K = 4 drops to 780 games/s; K >= 5
+    collapsed in every configuration tried.  Set k is
     bit-identical to a stand-alone BatchedSelfPlay(num_games_k, seed = seed * 64 + k): nothing is shared but the
     read-only packed weights."""
 
-    def __init__(self, model=None, num_games=2048, sims=50, num_sets=2, seed=0, device=None, **kw):
+    def __init__(self, model=None, num_games=2048, sims=50, num_sets=None, seed=0, device=None, **kw):
         self.dev = _lib.require_gpu(device)
+        if num_sets is None:                      # one hardware queue per set + the default stream, or fall back to 2
+            num_sets = 4 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 5 else 2
         k = max(1, min(int(num_sets), int(num_games)))
         sizes = [num_games // k + (1 if i < num_games % k else 0) for i in range(k)]
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in sizes]

@@ -72,8 +72,8 @@ def self_play(model=None, games=None):
     vis = torch.zeros((0, POLICY_OUTPUT_SIZE), dtype=torch.int16, device='cuda')
     z = torch.zeros((0,), dtype=torch.int8, device='cuda')
     if mine > 0:
-        # >= 256 games: two independent game sets on two streams fill the holes of each other's serial kernel chains
-        eng = MultiSetSelfPlay(model, num_games=mine, sims=pv_mcts.PV_EVALUATE_COUNT, num_sets=2 if mine >= 256 else 1,
+        # >= 256 games: independent game sets on their own streams fill the holes of each other's serial kernel chains
+        eng = MultiSetSelfPlay(model, num_games=mine, sims=pv_mcts.PV_EVALUATE_COUNT, num_sets=None if mine >= 256 else 1,
                                board_size=BOARD_SIZE, temperature=SP_TEMPERATURE, seed=1234 + rank)
         c = eng.play_generation()
         print(f'\rSelf-play (rank {rank}: {c["finished"]}/{mine} games)', end='')
