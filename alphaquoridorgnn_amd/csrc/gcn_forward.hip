@@ -53,7 +53,13 @@ struct PackedLayout {
     // layer-1 weight as fp16 B fragments with the split folded into the k dimension: per lane 8 halves,
     // k-slots 0..7 = hi(W1[n][0..5]),0,0   8..15 = lo(W1[n][0..5]),0,0   16..31 = 0:  [tile 8][lane 64][4 dwords]
     static constexpr size_t WH1 = WH3 + 2 * HID * HID / 2;
-    static constexpr size_t TOTAL = WH1 + 4 * 2 * 64 * 4;
+    // heads on the split matrix pipe (gcn_heads_mm_kernel): hidden layer of both heads as A fragments
+    // [plane 2][unit tile 8][kblock 4][lane 64][4 dwords]  (lane = unit 16*ut + c, k = 32*kb + 8*q + 0..7), and
+    // policy_head.2 as B fragments [plane 2][action tile 14][kblock 2][lane 64][4 dwords] (lane = action 16*at + c,
+    // k-slot (q, e) <-> hidden unit 32*kb + 16*(e >> 2) + 4*q + (e & 3): the order the layer-1 accumulators hold them)
+    static constexpr size_t WHH1 = WH1 + 4 * 2 * 64 * 4;
+    static constexpr size_t WHP2 = WHH1 + 2 * 8 * 4 * 64 * 4;
+    static constexpr size_t TOTAL = WHP2 + 2 * 14 * 2 * 64 * 4;
 };
 
 size_t packed_floats() { return PackedLayout::TOTAL; }
@@ -126,6 +132,40 @@ int pack_weights_host(int N, const float* const* t, float* out) {
                             }
                         }
                         dst[((w * 2 + j) * 64 + lane) * 4 + d] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+                    }
+    }
+    {
+        auto split2 = [](float x, uint16_t (&pl)[2]) {
+            const _Float16 h = (_Float16)x;
+            const _Float16 l = (_Float16)(x - (float)h);
+            memcpy(&pl[0], &h, 2); memcpy(&pl[1], &l, 2);
+        };
+        uint32_t* d1 = reinterpret_cast<uint32_t*>(out + PackedLayout::WHH1);
+        for (int ut = 0; ut < 8; ++ut)
+            for (int kb = 0; kb < 4; ++kb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int d = 0; d < 4; ++d) {
+                        const int c = lane & 15, q = lane >> 4, u = 16 * ut + c;
+                        uint16_t a[2], b[2];
+                        const int k = 32 * kb + 8 * q + 2 * d;
+                        const float* W = u < HID / 2 ? t[6] + (size_t)u * HID : t[10] + (size_t)(u - HID / 2) * HID;
+                        split2(W[k], a); split2(W[k + 1], b);
+                        for (int pl = 0; pl < 2; ++pl)
+                            d1[((((size_t)pl * 8 + ut) * 4 + kb) * 64 + lane) * 4 + d] = (uint32_t)a[pl] | ((uint32_t)b[pl] << 16);
+                    }
+        uint32_t* d2 = reinterpret_cast<uint32_t*>(out + PackedLayout::WHP2);
+        for (int at = 0; at < 14; ++at)
+            for (int kb = 0; kb < 2; ++kb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int d = 0; d < 4; ++d) {
+                        const int c = lane & 15, q = lane >> 4, act = 16 * at + c;
+                        uint16_t h[2][2] = {{0, 0}, {0, 0}};
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            const int e = 2 * d + e2, u = 32 * kb + 16 * (e >> 2) + 4 * q + (e & 3);
+                            if (act < A) split2(t[8][(size_t)act * (HID / 2) + u], h[e2]);
+                        }
+                        for (int pl = 0; pl < 2; ++pl)
+                            d2[((((size_t)pl * 14 + at) * 2 + kb) * 64 + lane) * 4 + d] = (uint32_t)h[0][pl] | ((uint32_t)h[1][pl] << 16);
                     }
     }
     for (int u = 0; u < HID / 2; ++u)
@@ -568,7 +608,6 @@ struct alignas(16) TrunkSmemM {
     alignas(16) unsigned int X0[96][4];                // node features as 8 fp16 (6 used); rows 81..95 stay zero
     alignas(16) float dinv[96];                        // deg^-1/2 per node; entries 81..95 stay zero
     alignas(16) float bias[3][HID];
-    unsigned int raw[20];                              // next board's record
 };
 static_assert(2 * sizeof(TrunkSmemM) <= 160 * 1024, "two workgroups per CU");
 
@@ -746,18 +785,29 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, q = lane >> 4;
 
-    const int ndw = fmt == 0 ? 18 : 6;
     int b = blockIdx.x;
     while (b < B && active && !active[b]) b += gridDim.x;
-    if (b < B && tid < ndw) sm.raw[tid] = reinterpret_cast<const uint32_t*>(states)[(size_t)b * ndw + tid];
-    // once per workgroup: padding rows that no board ever writes, and the three bias vectors
-    for (int i = tid; i < 96 * 4; i += NTHR) (&sm.X0[0][0])[i] = 0u;
-    if (tid < 96) sm.dinv[tid] = 0.f;
+    // A board's record lives in two VGPRs of EVERY wave (each wave fetches it itself: 24-72 bytes), one board ahead:
+    //   fmt 0 (state72): rec0 = wall byte of slot `lane`, rec1 = header dword;  fmt 1 (QState): rec0 = dword `lane` (< 5)
+    uint32_t rec0 = 0, rec1 = 0;
+    auto fetch_record = [&](int bb, uint32_t& r0, uint32_t& r1) {
+        if (fmt == 0) {
+            const uint8_t* r = reinterpret_cast<const uint8_t*>(states) + (size_t)bb * 72;
+            r0 = r[4 + lane];
+            r1 = *reinterpret_cast<const uint32_t*>(r);
+        } else {
+            r0 = reinterpret_cast<const uint32_t*>(states)[(size_t)bb * 6 + (lane < 5 ? lane : 4)];
+        }
+    };
+    if (b < B) fetch_record(b, rec0, rec1);
+    // once per workgroup: the padding rows no board ever writes, and the three bias vectors.  No barrier here: the first
+    // reader of any of it sits behind the first board's setup barrier.
+    if (tid < 15 * 4) (&sm.X0[81][0])[tid] = 0u;
+    if (tid < 15) sm.dinv[81 + tid] = 0.f;
     for (int i = tid; i < 3 * HID; i += NTHR) {
         const int L = i >> 7, k = i & 127;
         sm.bias[L][k] = pk[(L == 0 ? PackedLayout::B1 : L == 1 ? PackedLayout::B2 : PackedLayout::B3) + k];
     }
-    __syncthreads();
     u32x4 Bf[2][JT][4];
     const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
 
@@ -776,14 +826,13 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
             uint64_t hw, vw;
             uint32_t hd;
             if (fmt == 0) {
-                const uint32_t wb = reinterpret_cast<const uint8_t*>(sm.raw)[4 + lane];   // wall byte of slot `lane`: bit0 H, bit1 V
-                hw = __ballot((wb & 1u) != 0);
-                vw = __ballot((wb & 2u) != 0);
-                hd = __builtin_amdgcn_readfirstlane(sm.raw[0]);
+                hw = __ballot((rec0 & 1u) != 0);                             // wall byte: bit0 H, bit1 V
+                vw = __ballot((rec0 & 2u) != 0);
+                hd = __builtin_amdgcn_readfirstlane(rec1);
             } else {
-                hw = (uint64_t)__builtin_amdgcn_readfirstlane(sm.raw[0]) | ((uint64_t)__builtin_amdgcn_readfirstlane(sm.raw[1]) << 32);
-                vw = (uint64_t)__builtin_amdgcn_readfirstlane(sm.raw[2]) | ((uint64_t)__builtin_amdgcn_readfirstlane(sm.raw[3]) << 32);
-                hd = __builtin_amdgcn_readfirstlane(sm.raw[4]);
+                hw = (uint64_t)__builtin_amdgcn_readlane(rec0, 0) | ((uint64_t)__builtin_amdgcn_readlane(rec0, 1) << 32);
+                vw = (uint64_t)__builtin_amdgcn_readlane(rec0, 2) | ((uint64_t)__builtin_amdgcn_readlane(rec0, 3) << 32);
+                hd = __builtin_amdgcn_readlane(rec0, 4);
             }
             const Open op = make_open<N>(hw, vw);
             auto open_word = [&](const BB& m, int w) -> uint32_t { return w == 0 ? (uint32_t)m.lo : w == 1 ? (uint32_t)(m.lo >> 32) : (uint32_t)m.hi; };
@@ -805,9 +854,13 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
                                      ((open_word(op.L, w) >> sft) & 1u) + ((open_word(op.R, w) >> sft) & 1u);
                 sm.dinv[t] = dinv_of((int)deg);
             }
+            // ten adjacency blocks over the waves, the two waves that also write X0 / dinv getting the fewest:
+            //   8 waves: w0 {8}  w1 {9}  w2 {0,6}  w3 {1,7}  w4..7 {2..5}      4 waves: w0 {0,4}  w1 {1,5}  w2 {2,6,8}  w3 {3,7,9}
 #pragma unroll
-            for (int it = 0; it < (AF_BLOCKS + NWV - 1) / NWV; ++it) {
-                const int blk = wave + NWV * it;                             // wave-uniform
+            for (int it = 0; it < (NWV == 8 ? 2 : 3); ++it) {
+                int blk;                                                      // wave-uniform
+                if (NWV == 8) blk = it == 0 ? (wave >= 2 ? wave - 2 : wave + 8) : ((wave == 2 || wave == 3) ? wave + 4 : AF_BLOCKS);
+                else blk = it < 2 ? wave + 4 * it : (wave >= 2 ? wave + 6 : AF_BLOCKS);
                 if (blk < AF_BLOCKS) {
                     const int kb = (AF_KB_PACK >> (2 * blk)) & 3, nt = (AF_NT_PACK >> (3 * blk)) & 7;
                     int n = 16 * nt + c;
@@ -837,8 +890,6 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         while (bn < B && active && !active[bn]) bn += gridDim.x;
         __syncthreads();
         AQG_STAMP_AT(0)
-        uint32_t rawreg = 0;                                                // next board's record: one dword per lane
-        if (bn < B && tid < ndw) rawreg = reinterpret_cast<const uint32_t*>(states)[(size_t)bn * ndw + tid];
         f32x4 acc[6][JT], out[6][JT];
         // ---- layer 1: Z = X0 W1 (one MFMA per tile), aggregation, planes
 #pragma unroll
@@ -859,6 +910,8 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         stripe_matmul_mm<JT>(sm, Bf, lane, acc);
         AQG_STAMP_AT(2)
         load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH3, wave, lane);             // lands under the aggregation
+        uint32_t nrec0 = 0, nrec1 = 0;                                      // next board's record rides behind it (vmcnt retires
+        if (bn < B) fetch_record(bn, nrec0, nrec1);                         // in order: it is complete once layer 3 has its weights)
         __builtin_amdgcn_sched_barrier(0);
         AQG_STAMP_AT(11)
         adj_matmul<JT>(sm, acc, lane, out);
@@ -875,7 +928,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         adj_matmul<JT>(sm, acc, lane, out);
         AQG_STAMP_AT(15)
         adj_store<JT, true>(sm, out, 2, wave, lane, pooled + (size_t)b * HID);
-        if (tid < ndw) sm.raw[tid] = rawreg;
+        rec0 = nrec0; rec1 = nrec1;
         __syncthreads();                                                    // AF / X0 / dinv / planes are free for the next board
         AQG_STAMP_AT(5)
 #ifdef AQG_STAMP
@@ -1005,6 +1058,161 @@ __global__ __launch_bounds__(256) void gcn_heads_kernel(const float* __restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// heads on the split matrix pipe (default with trunk variants 3 / 4): one wave per 16 boards, no LDS.
+//   layer 1 (transposed):  hid^T[u][board] = HW1[u][k] pooled^T[k][board]   A = host-split weight fragments,
+//                          B = this lane's 8 consecutive pooled features of board (lane & 15), split in registers
+//   layer 2:               logits[board][a] = hid[board][u] PW2^T[u][a]     A = the layer-1 accumulators (lane = board,
+//                          4 consecutive units per tile -> k-slot order of WHP2), B = host-split weight fragments
+//   softmax in the accumulator layout (lane = action column, 4 boards per lane): in-lane over the 14 action tiles, then
+//   DPP row reductions over the 16 lanes of a row; value head on the VALU from the layer-1 accumulators.
+// Same split precision as the trunk (3 fp16 terms per product, f32 accumulate).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, u32x4& hi, u32x4& lo) {
+    hi = (u32x4){cvt_pk_f16(x0[0], x0[1]), cvt_pk_f16(x0[2], x0[3]), cvt_pk_f16(x1[0], x1[1]), cvt_pk_f16(x1[2], x1[3])};
+    const f32x4 r0 = x0 - f16_pairs_to_f32(hi[0], hi[1]), r1 = x1 - f16_pairs_to_f32(hi[2], hi[3]);
+    lo = (u32x4){cvt_pk_f16(r0[0], r0[1]), cvt_pk_f16(r0[2], r0[3]), cvt_pk_f16(r1[0], r1[1]), cvt_pk_f16(r1[2], r1[3])};
+}
+__device__ __forceinline__ float row16_max(float x) {
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false)));
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false)));
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false)));
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false)));
+    return x;
+}
+
+__global__ __launch_bounds__(64) void gcn_heads_mm_kernel(const float* __restrict__ pooled, int B, int A,
+                                                          const float* __restrict__ pk, float* __restrict__ logits,
+                                                          float* __restrict__ policy, float* __restrict__ value_pre,
+                                                          float* __restrict__ value, const uint8_t* __restrict__ active) {
+    const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
+    const int b0 = blockIdx.x * 16;
+    const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
+    constexpr int H1 = (int)(PackedLayout::WHH1 * sizeof(float)), P2 = (int)(PackedLayout::WHP2 * sizeof(float));
+    // first weight fragments go out before anything else
+    u32x4 af[2][2][4];                                         // [buffer][plane][kb]
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) af[0][pl][kb] = load_frag16(rs, lane * 16, H1 + ((pl * 8 + 0) * 4 + kb) * (64 * 16));
+    // B operand of layer 1: 32 pooled features of board (b0 + c), split
+    u32x4 ph[4], pl_[4];
+    {
+        const bool ok = b0 + c < B;
+        const float* row = pooled + (size_t)(ok ? b0 + c : B - 1) * HID + 8 * q;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            f32x4 x0 = *reinterpret_cast<const f32x4*>(row + 32 * kb), x1 = *reinterpret_cast<const f32x4*>(row + 32 * kb + 4);
+            if (!ok) { x0 = (f32x4){0.f, 0.f, 0.f, 0.f}; x1 = x0; }
+            split8(x0, x1, ph[kb], pl_[kb]);
+        }
+    }
+    u32x4 hh[2], hl[2];                                        // layer-2 A fragments: policy hidden units, [kb2]
+    float vsum = 0.f;
+#pragma unroll
+    for (int ut = 0; ut < 8; ++ut) {
+        if (ut < 7) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+                    af[(ut + 1) & 1][pl][kb] = load_frag16(rs, lane * 16, H1 + ((pl * 8 + ut + 1) * 4 + kb) * (64 * 16));
+        }
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            acc = mfma_f16(af[ut & 1][1][kb], ph[kb], acc);
+            acc = mfma_f16(af[ut & 1][0][kb], pl_[kb], acc);
+            acc = mfma_f16(af[ut & 1][0][kb], ph[kb], acc);
+        }
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(pk + PackedLayout::HB1 + 16 * ut + 4 * q);
+        f32x4 h = acc + bias;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
+        if (ut < 4) {
+            const unsigned int h01 = cvt_pk_f16(h[0], h[1]), h23 = cvt_pk_f16(h[2], h[3]);
+            const f32x4 r = h - f16_pairs_to_f32(h01, h23);
+            hh[ut >> 1][2 * (ut & 1)] = h01; hh[ut >> 1][2 * (ut & 1) + 1] = h23;
+            hl[ut >> 1][2 * (ut & 1)] = cvt_pk_f16(r[0], r[1]); hl[ut >> 1][2 * (ut & 1) + 1] = cvt_pk_f16(r[2], r[3]);
+        } else {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(pk + PackedLayout::VW2 + 16 * (ut - 4) + 4 * q);
+            vsum += h[0] * w[0] + h[1] * w[1] + h[2] * w[2] + h[3] * w[3];
+        }
+    }
+    // value head: the 4 lanes (q) of board c hold the partial sums
+    vsum += __shfl_xor(vsum, 16);
+    vsum += __shfl_xor(vsum, 32);
+    if (q == 0 && b0 + c < B && !(active && !active[b0 + c])) {
+        const float v = vsum + pk[PackedLayout::VB2];
+        if (value_pre) value_pre[b0 + c] = v;
+        if (value) value[b0 + c] = tanhf(v);
+    }
+    if (!logits && !policy) return;
+    // layer 2: logits tiles, lane = action 16*at + c, rows = boards 4q..4q+3
+    const int ntiles = (A + 15) >> 4;
+    f32x4 lg[14];
+    u32x4 bq[2][2][2];                                         // [buffer][plane][kb2]
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) bq[0][pl][kb] = load_frag16(rs, lane * 16, P2 + ((pl * 14 + 0) * 2 + kb) * (64 * 16));
+#pragma unroll
+    for (int at = 0; at < 14; ++at) {
+        lg[at] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (at < ntiles) {
+            if (at + 1 < 14) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+                        bq[(at + 1) & 1][pl][kb] = load_frag16(rs, lane * 16, P2 + ((pl * 14 + at + 1) * 2 + kb) * (64 * 16));
+            }
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                acc = mfma_f16(hl[kb], bq[at & 1][0][kb], acc);
+                acc = mfma_f16(hh[kb], bq[at & 1][1][kb], acc);
+                acc = mfma_f16(hh[kb], bq[at & 1][0][kb], acc);
+            }
+            const int a = 16 * at + c;
+            if (a < A) lg[at] = acc + pk[PackedLayout::PB2 + a];
+        }
+    }
+    // softmax per board (row i of every tile): max / sum over the tiles in-lane, then over the 16 lanes of the DPP row
+    f32x4 m = lg[0];
+#pragma unroll
+    for (int at = 1; at < 14; ++at)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], lg[at][i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = row16_max(m[i]);
+    f32x4 ssum = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ex[14];
+#pragma unroll
+    for (int at = 0; at < 14; ++at)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ex[at][i] = (16 * at + c < A) ? expf(lg[at][i] - m[i]) : 0.f;
+            ssum[i] += ex[at][i];
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ssum[i] = row16_sum(ssum[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int brd = b0 + 4 * q + i;
+        if (brd >= B || (active && !active[brd])) continue;
+#pragma unroll
+        for (int at = 0; at < 14; ++at) {
+            const int a = 16 * at + c;
+            if (a < A) {
+                if (logits) logits[(size_t)brd * A + a] = lg[at][i];
+                if (policy) policy[(size_t)brd * A + a] = ex[at][i] / ssum[i];
+            }
+        }
+    }
+}
+
 // Trunk variants (aqg_set_option("trunk_variant", v)):
 //   0 exact f32-input MFMA + VALU gather, weights resident, 1 workgroup/CU      1 the same, 2 workgroups/CU
 //   3 all-MFMA fp16 split trunk, 8 waves per board (16-column stripes, 4 waves per SIMD)  [default]
@@ -1096,6 +1304,11 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     if (g_profile_trunk) hipEventRecord(prof_event(), st);
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;
     if (!logits && !policy && !value_pre && !value) return 0;   // trunk only (bench: time the dominant kernel alone)
+    if (g_trunk_variant >= 3 && A <= 14 * 16) {
+        hipLaunchKernelGGL(gcn_heads_mm_kernel, dim3((B + 15) / 16), dim3(64), 0, st, (const float*)pooled, B, A, packed,
+                           logits, policy, value_pre, value, active);
+        return check_launch("gcn_heads_mm_kernel");
+    }
     hipLaunchKernelGGL(gcn_heads_kernel, dim3((B + HB - 1) / HB), dim3(256), 0, st, (const float*)pooled, B, A, packed,
                        logits, policy, value_pre, value, active);
     return check_launch("gcn_heads_kernel");

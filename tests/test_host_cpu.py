@@ -106,7 +106,9 @@ def test_weight_packing_layout():
     WF2 = 67396                                                            # offsets documented in include/aqgnn.h / gcn_forward.hip
     WH2 = WF2 + 2 * 128 * 128
     WH1 = WH2 + 2 * 2 * 128 * 128 // 2
-    assert n == WH1 + 4 * 2 * 64 * 4
+    WHH1 = WH1 + 4 * 2 * 64 * 4
+    WHP2 = WHH1 + 2 * 8 * 4 * 64 * 4
+    assert n == WHP2 + 2 * 14 * 2 * 64 * 4
     wf2 = out[WF2:WF2 + 128 * 128].reshape(4, 2, 8, 64, 4)                 # [wave][ntile][s4][lane][i]
     for (w, j, s4, lane, i) in [(0, 0, 0, 0, 0), (3, 1, 7, 63, 3), (2, 0, 5, 17, 2), (1, 1, 2, 40, 1)]:
         c, q = lane & 15, lane >> 4
@@ -131,6 +133,19 @@ def test_weight_packing_layout():
     cols = (32 * np.arange(4)[:, None, None] + 16 * np.arange(2)[None, :, None] + np.arange(16)[None, None, :])   # [wave][ntile][c]
     assert np.array_equal(w1[:, :, 0, :, :6], hi[cols].view(np.uint16)) and np.array_equal(w1[:, :, 1, :, :6], lo[cols].view(np.uint16))
     assert not w1[:, :, :2, :, 6:].any() and not w1[:, :, 2:].any()
+    # heads: hidden layer A fragments [plane][unit tile][kb][q][c][8 halves], policy B fragments in accumulator k order
+    hw = out[WHH1:WHP2].view(np.uint16).reshape(2, 8, 4, 4, 16, 8)
+    Wh = np.concatenate([p["policy_head.0.weight"], p["value_head.0.weight"]], 0).astype(np.float32)      # [128 units, 128]
+    hi = Wh.astype(np.float16); lo = (Wh - hi.astype(np.float32)).astype(np.float16)
+    ut, kb, q, c, e = np.meshgrid(np.arange(8), np.arange(4), np.arange(4), np.arange(16), np.arange(8), indexing="ij")
+    assert np.array_equal(hw[0], hi[16 * ut + c, 32 * kb + 8 * q + e].view(np.uint16))
+    assert np.array_equal(hw[1], lo[16 * ut + c, 32 * kb + 8 * q + e].view(np.uint16))
+    pw = out[WHP2:n].view(np.uint16).reshape(2, 14, 2, 4, 16, 8)
+    Wp = np.zeros((224, 64), np.float32); Wp[:209] = p["policy_head.2.weight"]
+    hi = Wp.astype(np.float16); lo = (Wp - hi.astype(np.float32)).astype(np.float16)
+    at, kb, q, c, e = np.meshgrid(np.arange(14), np.arange(2), np.arange(4), np.arange(16), np.arange(8), indexing="ij")
+    unit = 32 * kb + 16 * (e >> 2) + 4 * q + (e & 3)
+    assert np.array_equal(pw[0], hi[16 * at + c, unit].view(np.uint16)) and np.array_equal(pw[1], lo[16 * at + c, unit].view(np.uint16))
 
 
 _GLOO_WORKER = r'''
