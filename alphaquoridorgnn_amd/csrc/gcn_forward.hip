@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(256) void gcn_heads_kernel(const float* __restrict_
 
 
 // ---------------------------------------------------------------------------------------------
-// heads on the split matrix pipe (default with trunk variants 3 / 4): one wave per 16 boards, no LDS.
+// heads on the split matrix pipe (default with trunk variants 3 / 4): four waves per 16 boards.
 //   layer 1 (transposed):  hid^T[u][board] = HW1[u][k] pooled^T[k][board]   A = host-split weight fragments,
 //                          B = this lane's 8 consecutive pooled features of board (lane & 15), split in registers
 //   layer 2:               logits[board][a] = hid[board][u] PW2^T[u][a]     A = the layer-1 accumulators (lane = board,
@@ -1082,20 +1082,46 @@ __device__ __forceinline__ float row16_max(float x) {
     return x;
 }
 
-__global__ __launch_bounds__(64) void gcn_heads_mm_kernel(const float* __restrict__ pooled, int B, int A,
-                                                          const float* __restrict__ pk, float* __restrict__ logits,
-                                                          float* __restrict__ policy, float* __restrict__ value_pre,
-                                                          float* __restrict__ value, const uint8_t* __restrict__ active) {
-    const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
+struct alignas(16) HeadsSmem {
+    unsigned int hfrag[2][2][64][4];     // layer-2 A fragments [kb2][plane][lane]: written by waves 0 / 1, read by all
+    float vpart[2][16];                  // value-head partial sums of waves 2 / 3 per board
+    float wmax[4][16], wsum[4][16];      // per-wave softmax partials per board
+};
+
+// Four waves per 16 boards; every wave issues ALL its weight-fragment loads (32 x 16 B per lane) before anything else.
+//   phase 1: wave w computes hidden unit tiles 2w, 2w+1 (waves 0/1: policy hidden -> layer-2 A fragments into LDS,
+//            waves 2/3: value hidden -> value partial sums)                                         -- barrier --
+//   phase 2: wave w computes action tiles w, w+4, w+8, w+12 and its (max, sum exp) per board          -- barrier --
+//            every wave rescales its exponentials to the common maximum and stores its columns.
+__global__ __launch_bounds__(256, 2) void gcn_heads_mm_kernel(const float* __restrict__ pooled, int B, int A,
+                                                              const float* __restrict__ pk, float* __restrict__ logits,
+                                                              float* __restrict__ policy, float* __restrict__ value_pre,
+                                                              float* __restrict__ value, const uint8_t* __restrict__ active) {
+    __shared__ HeadsSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * 16;
     const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
     constexpr int H1 = (int)(PackedLayout::WHH1 * sizeof(float)), P2 = (int)(PackedLayout::WHP2 * sizeof(float));
-    // first weight fragments go out before anything else
-    u32x4 af[2][2][4];                                         // [buffer][plane][kb]
+    const int ntiles = (A + 15) >> 4;
+    const bool want_policy = logits || policy;
+    u32x4 af[2][2][4];                                         // [unit tile of this wave][plane][kb]
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) af[0][pl][kb] = load_frag16(rs, lane * 16, H1 + ((pl * 8 + 0) * 4 + kb) * (64 * 16));
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) af[t][pl][kb] = load_frag16(rs, lane * 16, H1 + ((pl * 8 + 2 * wave + t) * 4 + kb) * (64 * 16));
+    u32x4 bq[4][2][2];                                         // [action tile w + 4j][plane][kb2]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int at = wave + 4 * j;
+                bq[j][pl][kb] = (want_policy && at < ntiles) ? load_frag16(rs, lane * 16, P2 + ((pl * 14 + at) * 2 + kb) * (64 * 16)) : (u32x4){0u, 0u, 0u, 0u};
+            }
     // B operand of layer 1: 32 pooled features of board (b0 + c), split
     u32x4 ph[4], pl_[4];
     {
@@ -1108,107 +1134,123 @@ __global__ __launch_bounds__(64) void gcn_heads_mm_kernel(const float* __restric
             split8(x0, x1, ph[kb], pl_[kb]);
         }
     }
-    u32x4 hh[2], hl[2];                                        // layer-2 A fragments: policy hidden units, [kb2]
+    // ---- phase 1
+    u32x4 fh, fl;                                              // waves 0/1: this wave's layer-2 A fragment (kb2 = wave)
     float vsum = 0.f;
 #pragma unroll
-    for (int ut = 0; ut < 8; ++ut) {
-        if (ut < 7) {
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-                    af[(ut + 1) & 1][pl][kb] = load_frag16(rs, lane * 16, H1 + ((pl * 8 + ut + 1) * 4 + kb) * (64 * 16));
-        }
+    for (int t = 0; t < 2; ++t) {
+        const int ut = 2 * wave + t;
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            acc = mfma_f16(af[ut & 1][1][kb], ph[kb], acc);
-            acc = mfma_f16(af[ut & 1][0][kb], pl_[kb], acc);
-            acc = mfma_f16(af[ut & 1][0][kb], ph[kb], acc);
+            acc = mfma_f16(af[t][1][kb], ph[kb], acc);
+            acc = mfma_f16(af[t][0][kb], pl_[kb], acc);
+            acc = mfma_f16(af[t][0][kb], ph[kb], acc);
         }
         const f32x4 bias = *reinterpret_cast<const f32x4*>(pk + PackedLayout::HB1 + 16 * ut + 4 * q);
         f32x4 h = acc + bias;
 #pragma unroll
         for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
-        if (ut < 4) {
+        if (wave < 2) {
             const unsigned int h01 = cvt_pk_f16(h[0], h[1]), h23 = cvt_pk_f16(h[2], h[3]);
             const f32x4 r = h - f16_pairs_to_f32(h01, h23);
-            hh[ut >> 1][2 * (ut & 1)] = h01; hh[ut >> 1][2 * (ut & 1) + 1] = h23;
-            hl[ut >> 1][2 * (ut & 1)] = cvt_pk_f16(r[0], r[1]); hl[ut >> 1][2 * (ut & 1) + 1] = cvt_pk_f16(r[2], r[3]);
+            fh[2 * t] = h01; fh[2 * t + 1] = h23;
+            fl[2 * t] = cvt_pk_f16(r[0], r[1]); fl[2 * t + 1] = cvt_pk_f16(r[2], r[3]);
         } else {
             const f32x4 w = *reinterpret_cast<const f32x4*>(pk + PackedLayout::VW2 + 16 * (ut - 4) + 4 * q);
             vsum += h[0] * w[0] + h[1] * w[1] + h[2] * w[2] + h[3] * w[3];
         }
     }
-    // value head: the 4 lanes (q) of board c hold the partial sums
-    vsum += __shfl_xor(vsum, 16);
-    vsum += __shfl_xor(vsum, 32);
-    if (q == 0 && b0 + c < B && !(active && !active[b0 + c])) {
-        const float v = vsum + pk[PackedLayout::VB2];
-        if (value_pre) value_pre[b0 + c] = v;
-        if (value) value[b0 + c] = tanhf(v);
+    if (wave < 2) {
+        *reinterpret_cast<u32x4*>(&sm.hfrag[wave][0][lane][0]) = fh;
+        *reinterpret_cast<u32x4*>(&sm.hfrag[wave][1][lane][0]) = fl;
+    } else {
+        vsum += __shfl_xor(vsum, 16);
+        vsum += __shfl_xor(vsum, 32);
+        if (q == 0) sm.vpart[wave - 2][c] = vsum;
     }
-    if (!logits && !policy) return;
-    // layer 2: logits tiles, lane = action 16*at + c, rows = boards 4q..4q+3
-    const int ntiles = (A + 15) >> 4;
-    f32x4 lg[14];
-    u32x4 bq[2][2][2];                                         // [buffer][plane][kb2]
+    __syncthreads();
+    if (wave == 0 && lane < 16 && b0 + lane < B && !(active && !active[b0 + lane])) {
+        const float v = sm.vpart[0][lane] + sm.vpart[1][lane] + pk[PackedLayout::VB2];
+        if (value_pre) value_pre[b0 + lane] = v;
+        if (value) value[b0 + lane] = tanhf(v);
+    }
+    if (!want_policy) return;
+    // ---- phase 2: this wave's action tiles, lane = action 16*at + c, rows = boards 4q..4q+3
+    u32x4 hh[2], hl[2];
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+    for (int kb = 0; kb < 2; ++kb) {
+        hh[kb] = *reinterpret_cast<const u32x4*>(&sm.hfrag[kb][0][lane][0]);
+        hl[kb] = *reinterpret_cast<const u32x4*>(&sm.hfrag[kb][1][lane][0]);
+    }
+    f32x4 lg[4];
+    f32x4 m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) bq[0][pl][kb] = load_frag16(rs, lane * 16, P2 + ((pl * 14 + 0) * 2 + kb) * (64 * 16));
+    for (int j = 0; j < 4; ++j) {
+        const int at = wave + 4 * j, a = 16 * at + c;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int at = 0; at < 14; ++at) {
-        lg[at] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        if (at < ntiles) {
-            if (at + 1 < 14) {
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-                        bq[(at + 1) & 1][pl][kb] = load_frag16(rs, lane * 16, P2 + ((pl * 14 + at + 1) * 2 + kb) * (64 * 16));
-            }
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                acc = mfma_f16(hl[kb], bq[at & 1][0][kb], acc);
-                acc = mfma_f16(hh[kb], bq[at & 1][1][kb], acc);
-                acc = mfma_f16(hh[kb], bq[at & 1][0][kb], acc);
-            }
-            const int a = 16 * at + c;
-            if (a < A) lg[at] = acc + pk[PackedLayout::PB2 + a];
+        for (int kb = 0; kb < 2; ++kb) {
+            acc = mfma_f16(hl[kb], bq[j][0][kb], acc);
+            acc = mfma_f16(hh[kb], bq[j][1][kb], acc);
+            acc = mfma_f16(hh[kb], bq[j][0][kb], acc);
         }
-    }
-    // softmax per board (row i of every tile): max / sum over the tiles in-lane, then over the 16 lanes of the DPP row
-    f32x4 m = lg[0];
-#pragma unroll
-    for (int at = 1; at < 14; ++at)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], lg[at][i]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = row16_max(m[i]);
-    f32x4 ssum = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 ex[14];
-#pragma unroll
-    for (int at = 0; at < 14; ++at)
+        const bool ok = a < A;
+        const float pb = pk[PackedLayout::PB2 + (ok ? a : 0)];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ex[at][i] = (16 * at + c < A) ? expf(lg[at][i] - m[i]) : 0.f;
-            ssum[i] += ex[at][i];
+            lg[j][i] = ok ? acc[i] + pb : -INFINITY;
+            m[i] = fmaxf(m[i], lg[j][i]);
+        }
+    }
+    f32x4 ssum = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ex[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = row16_max(m[i]);          // this wave's maximum per board (finite: every wave owns tile w < 14)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ex[j][i] = __expf(lg[j][i] - m[i]);                // exp(-inf) = 0 for padded columns; ~2 ulp, far inside the tolerance
+            ssum[i] += ex[j][i];
         }
 #pragma unroll
     for (int i = 0; i < 4; ++i) ssum[i] = row16_sum(ssum[i]);
+    if (c == 0) {
+        *reinterpret_cast<f32x4*>(&sm.wmax[wave][4 * q]) = m;
+        *reinterpret_cast<f32x4*>(&sm.wsum[wave][4 * q]) = ssum;
+    }
+    __syncthreads();
+    // common maximum M, total S = sum_w s_w exp(m_w - M); this wave's exponentials are rescaled by exp(m_w - M) / S
+    f32x4 scale;
+    {
+        f32x4 mw[4], sw[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            mw[w] = *reinterpret_cast<const f32x4*>(&sm.wmax[w][4 * q]);
+            sw[w] = *reinterpret_cast<const f32x4*>(&sm.wsum[w][4 * q]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float M = fmaxf(fmaxf(mw[0][i], mw[1][i]), fmaxf(mw[2][i], mw[3][i]));
+            const float S = sw[0][i] * __expf(mw[0][i] - M) + sw[1][i] * __expf(mw[1][i] - M) + sw[2][i] * __expf(mw[2][i] - M) + sw[3][i] * __expf(mw[3][i] - M);
+            scale[i] = __expf(m[i] - M) / S;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int brd = b0 + 4 * q + i;
         if (brd >= B || (active && !active[brd])) continue;
+        const size_t row = (size_t)brd * A + 16 * wave + c;     // one 64-bit address per board row, this wave's tiles at +256 B steps
+        if (policy) {
+            float* __restrict__ p = policy + row;
 #pragma unroll
-        for (int at = 0; at < 14; ++at) {
-            const int a = 16 * at + c;
-            if (a < A) {
-                if (logits) logits[(size_t)brd * A + a] = lg[at][i];
-                if (policy) policy[(size_t)brd * A + a] = ex[at][i] / ssum[i];
-            }
+            for (int j = 0; j < 4; ++j) if (16 * (wave + 4 * j) + c < A) p[64 * j] = ex[j][i] * scale[i];
+        }
+        if (logits) {
+            float* __restrict__ l = logits + row;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (16 * (wave + 4 * j) + c < A) l[64 * j] = lg[j][i];
         }
     }
 }
@@ -1305,7 +1347,7 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;
     if (!logits && !policy && !value_pre && !value) return 0;   // trunk only (bench: time the dominant kernel alone)
     if (g_trunk_variant >= 3 && A <= 14 * 16) {
-        hipLaunchKernelGGL(gcn_heads_mm_kernel, dim3((B + 15) / 16), dim3(64), 0, st, (const float*)pooled, B, A, packed,
+        hipLaunchKernelGGL(gcn_heads_mm_kernel, dim3((B + 15) / 16), dim3(256), 0, st, (const float*)pooled, B, A, packed,
                            logits, policy, value_pre, value, active);
         return check_launch("gcn_heads_mm_kernel");
     }
