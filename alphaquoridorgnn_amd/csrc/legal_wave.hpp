@@ -29,17 +29,17 @@ __device__ __forceinline__ int wave_legal_actions(const QState& s, int lane, uin
         needV = placeV && possibly_blocking<N>(s.hw, s.vw, 2, lane);
     }
     const uint64_t pH = __ballot(placeH), pV = __ballot(placeV), nH = __ballot(needH), nV = __ballot(needV);
-    // Step 2 (lane = task): the searches are dealt out evenly -- task 2k / 2k+1 = the mover's / the enemy's flood
-    // fill for the k-th candidate that needs them (H candidates in slot order, then V) -- so no lane runs more
-    // than one fill per round, instead of up to four on the lane that owns a doubly-suspicious slot.
+    // Step 2 (lane = task): the k-th candidate that needs the searches (H candidates in slot order, then V) goes to
+    // lane k, which runs the mover's and the enemy's flood fill interleaved (can_reach2: two independent dependency
+    // chains keep a lone wavefront's VALU busy; one fill per lane and twice the rounds measured slower).
     const int cH = __popcll(nH), cV = __popcll(nV);
-    const int ntask = 2 * (cH + cV);
+    const int ntask = cH + cV;
     uint64_t failH = 0, failV = 0;
     for (int tbase = 0; tbase < ntask; tbase += 64) {
         const int task = tbase + lane;
         uint64_t myfailH = 0, myfailV = 0;
         if (task < ntask) {
-            const int k = task >> 1;
+            const int k = task;
             const int orient = k < cH ? 1 : 2;
             uint64_t m = orient == 1 ? nH : nV;
             int rank = orient == 1 ? k : k - cH;
@@ -52,9 +52,8 @@ __device__ __forceinline__ int wave_legal_actions(const QState& s, int lane, uin
             }
             const Open o = add_wall<N>(base, orient, slot);
             const int me = s.ppos, other = V - 1 - s.epos;
-            const bool ok = (task & 1) == 0 ? can_reach<N>(o, me, other, mask_row<N>(0))
-                                            : can_reach<N>(o, other, me, mask_row<N>(N - 1));
-            if (!ok) { if (orient == 1) myfailH = 1ull << slot; else myfailV = 1ull << slot; }
+            const int ok = can_reach2<N>(o, me, other, mask_row<N>(0), other, me, mask_row<N>(N - 1));
+            if (ok != 3) { if (orient == 1) myfailH = 1ull << slot; else myfailV = 1ull << slot; }
         }
         // wave-wide OR of the failure bits
 #pragma unroll

@@ -256,6 +256,37 @@ template <int N> QHD bool can_reach(const Open& o, int start, int obst, BB goal)
     return bb_any(reach & goal);
 }
 
+// The two searches a wall candidate needs (mover -> its goal row, enemy -> its goal row) advanced in lock step.
+// Same decisions as two can_reach() calls -- each search is decided at the iteration at which it would be alone --
+// but the two dependency chains are independent, so a wavefront that has its SIMD to itself issues them
+// back to back instead of waiting out each instruction's latency.  Returns bit0 = A reaches, bit1 = B reaches.
+template <int N> QHD int can_reach2(const Open& o, int sA, int obA, BB goalA, int sB, int obB, BB goalB) {
+    const Jumps jA = make_jumps<N>(o, obA), jB = make_jumps<N>(o, obB);
+    const BB nA = ~bb_bit(obA), nB = ~bb_bit(obB);
+    BB rA = bb_bit(sA), rB = bb_bit(sB);
+    int res = 0, done = 0;
+    for (int it = 0; it < N * N; ++it) {
+        if (!(done & 1) && bb_any(rA & goalA)) { res |= 1; done |= 1; }
+        if (!(done & 2) && bb_any(rB & goalB)) { res |= 2; done |= 2; }
+        if (done == 3) break;
+        BB a = rA | bb_shl<N>(rA & o.D) | bb_shr<N>(rA & o.U) | bb_shl<1>(rA & o.R) | bb_shr<1>(rA & o.L);
+        BB b = rB | bb_shl<N>(rB & o.D) | bb_shr<N>(rB & o.U) | bb_shl<1>(rB & o.R) | bb_shr<1>(rB & o.L);
+        a = a & nA; b = b & nB;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            if (jA.p[d] >= 0 && bb_test(rA, jA.p[d])) a = a | jA.J[d];
+            if (jB.p[d] >= 0 && bb_test(rB, jB.p[d])) b = b | jB.J[d];
+        }
+        if (bb_eq(a, rA)) done |= 1;                       // fixpoint without the goal: this search has failed
+        if (bb_eq(b, rB)) done |= 2;
+        if (done == 3) break;
+        rA = a; rB = b;
+    }
+    if (!(done & 1) && bb_any(rA & goalA)) res |= 1;
+    if (!(done & 2) && bb_any(rB & goalB)) res |= 2;
+    return res;
+}
+
 // game_logic.py:120-192 legal_actions_pos(pos) with the enemy pawn on tile `e` (mover's frame).
 // Ordered: U, D, L, R; a jump contributes the straight landing, else (left,right) / (up,down).
 template <int N> QHD int legal_pos_list(const Open& o, int pos, int e, uint8_t* out) {
@@ -329,8 +360,11 @@ template <int N> QHD bool wall_keeps_paths(const QState& s, const Open& base, in
     constexpr int V = N * N;
     const Open o = add_wall<N>(base, orient, pos);
     const int me = s.ppos, other = V - 1 - s.epos;                     // :136 enemy in mover's frame
-    bool rp = can_reach<N>(o, me, other, mask_row<N>(0));              // :335
-    bool re = can_reach<N>(o, other, me, mask_row<N>(N - 1));          // :344-345, un-rotated
+    const bool rp = can_reach<N>(o, me, other, mask_row<N>(0));        // :335
+    const bool re = can_reach<N>(o, other, me, mask_row<N>(N - 1));    // :344-345, un-rotated
+    // the lock-step form the GPU wavefront uses must decide exactly the same (host tests run this against every fixture)
+    const int both = can_reach2<N>(o, me, other, mask_row<N>(0), other, me, mask_row<N>(N - 1));
+    if (both != ((rp ? 1 : 0) | (re ? 2 : 0))) return !(rp && re);    // a disagreement flips the answer and fails the golden tests
     return rp && re;
 }
 
