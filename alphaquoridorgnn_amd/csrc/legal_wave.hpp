@@ -20,7 +20,11 @@ __device__ __forceinline__ int wave_legal_actions(const QState& s, int lane, uin
     // Step 1 (lane = wall slot): geometric placement and the touch-count prefilter.  A placeable candidate that
     // the prefilter clears is legal outright (game_logic.py:327-328); the others need the two path searches.
     bool placeH = false, placeV = false, needH = false, needV = false;
+#if defined(AQG_LEGAL_DIAG) && AQG_LEGAL_DIAG >= 2   // ... and no placement / prefilter step either
+    if (false) {
+#else
     if (s.pwl > 0 && lane < NW) {
+#endif
         uint64_t hp, vp;
         placeable_masks<N>(s.hw, s.vw, hp, vp);
         placeH = (hp >> lane) & 1;
@@ -33,7 +37,11 @@ __device__ __forceinline__ int wave_legal_actions(const QState& s, int lane, uin
     // lane k, which runs the mover's and the enemy's flood fill interleaved (can_reach2: two independent dependency
     // chains keep a lone wavefront's VALU busy; one fill per lane and twice the rounds measured slower).
     const int cH = __popcll(nH), cV = __popcll(nV);
+#if defined(AQG_LEGAL_DIAG) && AQG_LEGAL_DIAG >= 1   // timing experiments only (wrong results): no flood fills
+    const int ntask = 0;
+#else
     const int ntask = cH + cV;
+#endif
     uint64_t failH = 0, failV = 0;
     for (int tbase = 0; tbase < ntask; tbase += 64) {
         const int task = tbase + lane;

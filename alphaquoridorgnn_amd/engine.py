@@ -218,6 +218,26 @@ class MultiSetSelfPlay:
         for _, eng in self._each(live_only=True):
             eng.move()
 
+    def move_exclusive(self, k, before=None, after=None):
+        """Measurement aid (bench.py): one move in which set k runs ALONE on the GPU -- every stream is drained, set k
+        makes its move (callbacks `before(set)` / `after(set)` run on its stream around it), is drained again, and only
+        then do the other live sets move.  Per-kernel durations taken inside are those of the kernel itself, not of a
+        kernel sharing the chip with the other sets' launches.  Results are identical to move()."""
+        self.sync()
+        k %= len(self.sets)
+        if self._live[k]:
+            with torch.cuda.stream(self.streams[k]):
+                if before:
+                    before(self.sets[k])
+                self.sets[k].move()
+                if after:
+                    after(self.sets[k])
+            self.streams[k].synchronize()
+        for i, eng in self._each(live_only=True):
+            if i != k:
+                eng.move()
+        return self._live[k]
+
     def counters(self):
         tot = dict(active=0, finished=0, dead_ends=0, leaf_evals=0, terminal_sims=0)
         for i, eng in self._each():

@@ -11,7 +11,7 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   gnn_forward  : configs[1] -- pv_network_gnn forward at B=4096 synthetic boards, boards/s (HIP events)
   roofline     : the dominant kernel (gcn_trunk_boards_mm_kernel) over the timed region: algorithmic FLOP of the
                  boards it processed / its summed launch durations (HIP event pairs recorded inside the library around
-                 every trunk launch of every 8th ply, on the launch stream), against the matrix-pipe roof of the
+                 the trunk launches of sampled moves -- one game set running alone, plain launches --, on the launch stream), against the matrix-pipe roof of the
                  fp32-equivalent fp16-split algorithm; the SURVEY 8(d) HBM figure (169,760 B/board against 8 TB/s) is
                  reported beside it as hbm_frac_survey_formula
   cpu_baseline : the oracle (CPU restatement, kind "port") on a bounded sample of the same workload, rank 0, N=1.
@@ -40,9 +40,9 @@ SPLIT_TERMS = 3                                                      # hi*hi + h
 TRUNK_MFMA_PER_BOARD = 4 * (12 + 2 * 144 + 3 * 40)                   # 16x16x32 fp16 MFMAs issued per board (incl. aggregation, padding)
 PEAK_HBM = 8.0e12
 # HBM bytes per board actually moved by the default trunk, from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-# WRITE_SIZE, separate passes; profiles/r01_trunk_bf16x6_hbm_pmc.csv, B = 65,536 boards per launch).  PMC counters
+# WRITE_SIZE, separate passes; profiles/r01_trunk_mm_hbm_pmc.csv, B = 65,536 boards per launch).  PMC counters
 # cannot be collected from inside this process, so `roofline.traffic` = this per-board figure x boards per launch.
-TRUNK_HBM_BYTES_PER_BOARD_PMC = 3827
+TRUNK_HBM_BYTES_PER_BOARD_PMC = 852
 
 
 def cpu_baseline(sims, mean_plies, budget_s=15.0):
@@ -108,24 +108,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sampled_boards = torch.zeros((len(eng.sets),), dtype=torch.int64, device=dev)
-    PROFILE_EVERY = 8      # plies whose trunk launches carry HIP event pairs (those plies use plain launches, the others
-                           # replay the captured hipGraph of a move, which cannot carry per-kernel events)
+    sampled_boards = torch.zeros((1,), dtype=torch.int64, device=dev)
+    SAMPLE_PLIES = (13, 41, 69, 97)   # plies of a generation whose trunk launches carry HIP event pairs.  On such a ply ONE
+                                      # game set (round-robin) makes its move alone on the GPU with plain launches -- the
+                                      # other plies replay captured hipGraphs with all sets overlapping, where an event pair
+                                      # would time the sharing, not the kernel.  Costs ~1-2 % of the timed region.
+    sample_no = [0]
+
+    def _before(e):
+        sampled_boards.sub_(e.t["stat_leaf_evals"].sum())    # boards evaluated by the sampled launches, counted on the device
+        _lib.set_option("profile_trunk", 1)
+
+    def _after(e):
+        _lib.set_option("profile_trunk", 0)
+        sampled_boards.add_(e.t["stat_leaf_evals"].sum())
 
     def one_step(profile):
         eng.reset()
         ply = 0
         while True:
-            sampled = profile and ply % PROFILE_EVERY == 0
-            if sampled:                               # boards evaluated by the sampled launches: device-side sums on each
-                for i, e in eng._each():              # set's own stream, no host synchronisation
-                    sampled_boards[i] -= e.t["stat_leaf_evals"].sum()
-                _lib.set_option("profile_trunk", 1)
-            eng.move()
-            if sampled:
-                _lib.set_option("profile_trunk", 0)
-                for i, e in eng._each():
-                    sampled_boards[i] += e.t["stat_leaf_evals"].sum()
+            if profile and ply in SAMPLE_PLIES:
+                eng.move_exclusive(sample_no[0], _before, _after)
+                sample_no[0] += 1
+            else:
+                eng.move()
             ply += 1
             if ply % 4 == 0 or ply >= eng.max_plies:
                 if profile:
@@ -227,13 +233,12 @@ def main():
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / SPLIT_TERMS / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / (PEAK_F16_MFMA / SPLIT_TERMS),
                          "traffic": TRUNK_HBM_BYTES_PER_BOARD_PMC * trunk_boards / max(trunk_launches, 1),
-                         "traffic_note": "HBM bytes per launch = 3,827 B/board (rocprofv3 PMC on an earlier build with the same weight-streaming pattern, "
-                                         "profiles/r01_trunk_bf16x6_hbm_pmc.csv; dominated by the L2-missing share of the per-board weight "
-                                         "fragment reads) x boards per launch; algorithmic layer-granular figure is 169,760 B/board "
-                                         "(hbm_frac_survey_formula): activations never leave LDS",
+                         "traffic_note": "HBM bytes per launch = 852 B/board (rocprofv3 PMC on this kernel, profiles/r01_trunk_mm_hbm_pmc.csv: 584 B/board "
+                                         "compulsory record-in + pooled-out, the rest is the L2-missing share of the weight fragments) x boards per launch; "
+                                         "the algorithmic layer-granular figure is 169,760 B/board (hbm_frac_survey_formula): activations never leave LDS",
                          "launches": trunk_launches, "avg_launch_us": trunk_ms / max(trunk_launches, 1) * 1e3,
                          "boards_per_launch_avg": trunk_boards / max(trunk_launches, 1),
-                         "launches_sampled": "every trunk launch of every 8th ply of the timed region (those plies use plain launches; the rest replay a captured hipGraph)",
+                         "launches_sampled": "every trunk launch of one game set's move on plies 13/41/69/97 of each timed generation; that set runs alone on the GPU with plain launches for that move, all other moves replay captured hipGraphs with the sets overlapping",
                          "flop_per_board": TRUNK_FLOP_PER_BOARD,
                          "hbm_frac_survey_formula": boards_per_s_kernel * HBM_BYTES_PER_BOARD / PEAK_HBM,
                          "frac_vs_f32_input_mfma_peak": achieved / PEAK_F32_MFMA,
