@@ -157,3 +157,28 @@ def play(model, sims, temperature=1.0, N=9, uniforms=None, rng=None, max_plies=N
         h[2] = value
         value = -value
     return history
+
+
+def first_player_point(ended_state):
+    """evaluate_network.py:18-22: 1 first player wins, 0 loses, 0.5 draw."""
+    if ended_state.is_lose():
+        return 0 if ended_state.is_first_player() else 1
+    return 0.5
+
+
+def evaluate_play(model_first, model_second, sims, temperature=1.0, N=9, uniforms=None, rng=None):
+    """evaluate_network.py:25-44 `play(next_actions)` with next_actions = (pv_mcts_action(model_first),
+    pv_mcts_action(model_second)) (pv_mcts.py:98-104): the mover's own model searches from a fresh tree, the action is
+    np.random.choice(legal, p=scores) -- one uniform per move.  Returns (first player's point, list of actions)."""
+    state = quoridor.State(N=N)
+    it = iter(uniforms) if uniforms is not None else None
+    actions = []
+    while not state.is_done():
+        model = model_first if state.is_first_player() else model_second
+        scores = pv_mcts_policy(model, state, temperature, sims)
+        legal = state.legal_actions()
+        u = next(it) if it is not None else rng.random_sample()
+        a = legal[choice_index(scores, u)]
+        actions.append(int(a))
+        state = state.next(a)
+    return first_player_point(state), actions

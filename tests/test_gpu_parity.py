@@ -256,6 +256,62 @@ def test_selfplay_games_match_reference(dev, N):
             assert z == int(g[f"g{i}_z"][j])
 
 
+@pytest.mark.parametrize("N", [9, 5])
+def test_evaluation_games_match_reference(dev, N):
+    """evaluate_network row: a two-model game on the engine == the reference's evaluate_network.play()
+    with two fake models through pv_mcts_action (tools/gen_golden_eval.py): same action on every ply, same point."""
+    from alphaquoridorgnn_amd.evaluate_network import BatchedMatch
+    g = U.golden(f"eval_{N}x{N}.npz")
+    for i in range(int(g["count"][0])):
+        seed, sims, b0, b1 = (int(x) for x in g[f"e{i}_cfg"])
+        m = BatchedMatch((b0, b1), 1, sims=sims, board_size=N, evaluator="fake")
+        eng = m.engines[0]
+        u = np.random.RandomState(seed).random_sample(size=(eng.max_plies, 1))   # one uniform per move (np.random.choice)
+        points = m.play(uniforms=(torch.from_numpy(u), None))
+        ref_actions = g[f"e{i}_actions"]
+        plies = int(eng.t["game_plies"][0])
+        assert plies == len(ref_actions)
+        assert np.array_equal(eng.t["hist_action"][0, :plies].cpu().numpy().astype(np.int16), ref_actions)
+        assert points == [float(g[f"e{i}_point"][0])]
+
+
+def test_batched_match_colours_and_points(dev):
+    """BatchedMatch bookkeeping: game i has player i % 2 moving first, points are player 0's, and a batch of games equals
+    the same games played one at a time (fake evaluator, explicit uniforms)."""
+    from alphaquoridorgnn_amd.evaluate_network import BatchedMatch
+    rng = np.random.RandomState(3)
+    G = 5
+    m = BatchedMatch((40, 0), G, sims=8, board_size=5, evaluator="fake")
+    ua = rng.random_sample(size=(m.engines[0].max_plies, 3))
+    ub = rng.random_sample(size=(m.engines[1].max_plies, 2))
+    pts = m.play(uniforms=(torch.from_numpy(ua), torch.from_numpy(ub)))
+    assert len(pts) == G and all(p in (0.0, 0.5, 1.0) for p in pts)
+    for i in range(G):
+        first, col = i % 2, i // 2
+        one = BatchedMatch((40, 0) if first == 0 else (0, 40), 1, sims=8, board_size=5, evaluator="fake")
+        u = (ua if first == 0 else ub)[:, col:col + 1]
+        p = one.play(uniforms=(torch.from_numpy(np.ascontiguousarray(u)), None))[0]
+        assert pts[i] == (p if first == 0 else 1.0 - p)
+
+
+def test_evaluate_network_with_gnn(dev, tmp_path, monkeypatch):
+    """evaluate_network() end to end with two random GNNs saved as latest.pth / best.pth: returns a bool and promotes
+    by copying the file exactly when it says so (evaluate_network.py:90-94)."""
+    from alphaquoridorgnn_amd import evaluate_network as en, pv_mcts
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+    monkeypatch.setattr(pv_mcts, "PV_EVALUATE_COUNT", 6)
+    monkeypatch.setattr(en, "EN_GAME_COUNT", 6)
+    path = str(tmp_path) + "/"
+    monkeypatch.setattr(en, "PV_NETWORK_PATH", path)
+    torch.manual_seed(1); torch.save(GNNNetwork().state_dict(), path + "latest.pth")
+    torch.manual_seed(2); torch.save(GNNNetwork().state_dict(), path + "best.pth")
+    before = open(path + "best.pth", "rb").read()
+    promoted = en.evaluate_network()
+    after = open(path + "best.pth", "rb").read()
+    assert isinstance(promoted, bool)
+    assert (after == open(path + "latest.pth", "rb").read()) if promoted else (after == before)
+
+
 def test_mcts_many_games_equal_single_game(dev):
     """Lock-step batching must not couple games: 257 copies of different roots == each searched alone (oracle)."""
     from alphaquoridorgnn_amd.pv_mcts import pv_mcts_policy_batch

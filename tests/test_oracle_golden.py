@@ -114,6 +114,20 @@ def test_full_games_match_reference(N):
             assert z == int(g[f"g{i}_z"][j])
 
 
+@pytest.mark.parametrize("N", [9, 5])
+def test_evaluation_games_match_reference(N):
+    """evaluate_network.play() of the reference (two fake models through pv_mcts_action, tools/gen_golden_eval.py)."""
+    g = U.golden(f"eval_{N}x{N}.npz")
+    for i in range(int(g["count"][0])):
+        seed, sims, b0, b1 = (int(x) for x in g[f"e{i}_cfg"])
+        if N == 9 and len(g[f"e{i}_actions"]) > 30:
+            continue  # the longer 9x9 games run on the GPU engine test
+        rng = np.random.RandomState(seed)
+        point, actions = om.evaluate_play(om.FakeModel(b0), om.FakeModel(b1), sims, 1.0, N=N, rng=rng)
+        assert actions == [int(a) for a in g[f"e{i}_actions"]]
+        assert point == float(g[f"e{i}_point"][0])
+
+
 def test_choice_index_matches_numpy():
     rng = np.random.RandomState(5)
     for _ in range(200):
