@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQG_LIB_PATH", os.path.join(_HERE, "libaqgnn_hip.so"))  # override: diagnostic builds only
 MAX_LEGAL = 136
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c = ctypes
 _vp, _i32, _f32 = _c.c_void_p, _c.c_int32, _c.c_float
@@ -33,6 +33,17 @@ class EngineStruct(_c.Structure):
     )
 
 
+class TrainStruct(_c.Structure):
+    """Mirror of `struct aqg_train` (include/aqgnn.h)."""
+    _fields_ = (
+        [(n, _i32) for n in ("board_size", "batch", "policy_size", "step")]
+        + [(n, _f32) for n in ("lr", "beta1", "beta2", "eps")]
+        + [(n, _vp * 14) for n in ("params", "grads", "adam_m", "adam_v")]
+        + [(n, _vp) for n in ("x0", "ell_idx", "ell_w", "zbuf", "h1", "h2", "h3", "dh", "g", "dg", "hp", "hv", "dhp", "dhv",
+                              "lg", "pol", "vp", "val", "loss")]
+    )
+
+
 SIGNATURES = {
     "aqg_abi_version": (_c.c_int, []),
     "aqg_last_error": (_c.c_char_p, []),
@@ -51,6 +62,7 @@ SIGNATURES = {
     "aqg_engine_move": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp]),
     "aqg_engine_search": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp]),
     "aqg_engine_root_visits": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp, _vp, _vp]),
+    "aqg_gcn_train_step": (_c.c_int, [_c.POINTER(TrainStruct), _vp, _vp, _vp, _c.c_int, _vp]),
 }
 
 _lib = None

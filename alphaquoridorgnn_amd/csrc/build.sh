@@ -7,7 +7,7 @@ OUT=../libaqgnn_hip.so
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function"
 OBJDIR=${OBJDIR:-$(mktemp -d)}
 objs=()
-for f in legal_mask gcn_forward mcts capi; do
+for f in legal_mask gcn_forward gcn_train mcts capi; do
   $HIPCC $FLAGS -c $f.hip -o ${OBJDIR}/aqg_$f.o &
   objs+=(${OBJDIR}/aqg_$f.o)
 done

@@ -89,12 +89,14 @@ class GraphPolicyValueNetwork(nn.Module):
             _lib.check(lib.aqg_gcn_pack_weights_host(self.board_size, arr, ctypes.c_void_p(out.data_ptr())),
                        "aqg_gcn_pack_weights_host")
             self._packed = out.to(device)
-            # One-time cost per weight refresh: make the upload globally visible before any kernel reads it.  Without
-            # it the first launch after a fresh upload was observed (rarely, MI355X / ROCm 7.2) to read a not-yet-
-            # complete tail of the buffer (the bf16 fragment planes) -- see DESIGN.md section 3.
-            torch.cuda.current_stream(device).synchronize()
             self._packed_key = key
         return self._packed
+
+    def invalidate_packed(self):
+        """Call after the parameters were changed behind torch's back (train_network.GNNTrainer updates them in place from
+        a HIP kernel, which does not bump the tensors' version counters)."""
+        self._packed = None
+        self._packed_key = None
 
     # ---------------------------------------------------------------- fused board path
     def forward_states(self, states72, want_logits=False, state_fmt=0):

@@ -1,0 +1,134 @@
+"""Parameter update -- drop-in for the reference's train_network.py, on the GNN, with the whole optimisation step in HIP.
+
+Call surface kept (train_network.py:14-107): NUM_EPOCH, BATCH_SIZE, load_data, train_network.  One step = one C call
+(`aqg_gcn_train_step`, csrc/gcn_train.hip): forward, the reference's losses (CrossEntropyLoss on the already-softmaxed
+policy + MSELoss, train_network.py:54-55,85-86), backward, Adam (:56,:90-92), all fp32.  The parameters updated are the
+model's own state_dict tensors; torch is used for memory, shuffling and the .pth / .history files only.
+"""
+import ctypes
+import pickle
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import _lib
+from .constants import PV_NETWORK_PATH, BOARD_SIZE
+from .pv_network_gnn import GNNNetwork, STATE_DICT_KEYS, HIDDEN_DIM, NUM_FEATURES
+
+NUM_EPOCH = 100    # train_network.py:14
+BATCH_SIZE = 128   # train_network.py:15
+LEARNING_RATE = 0.001   # train_network.py:56
+
+
+def load_data():
+    """Load the latest training data (train_network.py:19-23).  The file is this build's own self_play.write_data()
+    output (same schema as the reference's)."""
+    history_path = sorted(Path('./data').glob('*.history'))[-1]
+    with history_path.open(mode='rb') as f:
+        return pickle.load(f)
+
+
+def lr_lambda(epoch):
+    """train_network.py:59-65."""
+    if epoch >= 80:
+        return 0.25
+    elif epoch >= 50:
+        return 0.5
+    return 1.0
+
+
+class GNNTrainer:
+    """Adam state + workspace for optimisation steps of up to `max_batch` positions on `model` (a GNNNetwork on the GPU)."""
+
+    def __init__(self, model, max_batch=BATCH_SIZE, betas=(0.9, 0.999), eps=1e-8):
+        self.model = model
+        self.lib = _lib.load()
+        sd = model.state_dict()
+        self.params = [sd[k] for k in STATE_DICT_KEYS]
+        self.dev = _lib.require_gpu(self.params[0].device)
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError("training needs contiguous float32 parameters")
+        self.grads = [torch.zeros_like(p) for p in self.params]
+        self.adam_m = [torch.zeros_like(p) for p in self.params]
+        self.adam_v = [torch.zeros_like(p) for p in self.params]
+        self.N = model.board_size
+        self.V = self.N * self.N
+        self.A = model.policy_output_size
+        self.max_batch = int(max_batch)
+        self.step_count = 0
+        self.betas, self.eps = betas, eps
+        B, V, A, H = self.max_batch, self.V, self.A, HIDDEN_DIM
+        f = dict(dtype=torch.float32, device=self.dev)
+        w = self.ws = dict(
+            x0=torch.empty((B * V, NUM_FEATURES), **f), ell_idx=torch.empty((B * V, 5), dtype=torch.int32, device=self.dev),
+            ell_w=torch.empty((B * V, 5), **f), zbuf=torch.empty((B * V, H), **f), h1=torch.empty((B * V, H), **f),
+            h2=torch.empty((B * V, H), **f), h3=torch.empty((B * V, H), **f), dh=torch.empty((B * V, H), **f),
+            g=torch.empty((B, H), **f), dg=torch.empty((B, H), **f), hp=torch.empty((B, H // 2), **f),
+            hv=torch.empty((B, H // 2), **f), dhp=torch.empty((B, H // 2), **f), dhv=torch.empty((B, H // 2), **f),
+            lg=torch.empty((B, A), **f), pol=torch.empty((B, A), **f), vp=torch.empty((B,), **f), val=torch.empty((B,), **f),
+            loss=torch.empty((B, 2), **f))
+        t = self.t = _lib.TrainStruct()
+        t.board_size, t.policy_size = self.N, self.A
+        t.beta1, t.beta2, t.eps = float(betas[0]), float(betas[1]), float(eps)
+        for name, tensors in (("params", self.params), ("grads", self.grads), ("adam_m", self.adam_m), ("adam_v", self.adam_v)):
+            arr = getattr(t, name)
+            for i, x in enumerate(tensors):
+                arr[i] = x.data_ptr()
+        for name, x in w.items():
+            setattr(t, name, x.data_ptr())
+
+    def step(self, states72, pi_target, z_target, lr=LEARNING_RATE, update=True):
+        """One optimisation step.  states72 uint8 [B,72], pi_target float32 [B,A], z_target float32 [B] (device tensors).
+        Returns (policy_loss, value_loss) as 0-dim device tensors -- no host synchronisation."""
+        B = int(states72.shape[0])
+        if B > self.max_batch:
+            raise ValueError("batch larger than the trainer's workspace")
+        states72 = states72.to(self.dev, torch.uint8).contiguous()
+        pi_target = pi_target.to(self.dev, torch.float32).contiguous()
+        z_target = z_target.to(self.dev, torch.float32).contiguous()
+        if update:
+            self.step_count += 1
+        self.t.batch, self.t.step, self.t.lr = B, max(self.step_count, 1), float(lr)
+        _lib.check(self.lib.aqg_gcn_train_step(ctypes.byref(self.t), _lib.ptr(states72), _lib.ptr(pi_target), _lib.ptr(z_target),
+                                               1 if update else 0, _lib.stream_ptr(self.dev)), "aqg_gcn_train_step")
+        if update:
+            self.model.invalidate_packed()
+        loss = self.ws["loss"][:B].mean(dim=0)
+        return loss[0], loss[1]
+
+    def outputs(self, B):
+        """(policy [B,A], value [B]) of the last step's forward pass."""
+        return self.ws["pol"][:B], self.ws["val"][:B]
+
+
+def train_network():
+    """train_network.py:26-107 on the GNN: best.pth -> NUM_EPOCH epochs over the newest .history -> latest.pth."""
+    model = GNNNetwork()
+    model.load_state_dict(torch.load(PV_NETWORK_PATH + 'best.pth', map_location='cuda', weights_only=True))
+    model = model.to('cuda')
+    history = load_data()
+    s, p, v = zip(*history)
+    s = torch.from_numpy(model.preprocess_input(s)).to('cuda')                     # uint8 [n,72]
+    p = torch.tensor(np.array(p), dtype=torch.float32, device='cuda')              # policy targets
+    v = torch.tensor(np.array(v), dtype=torch.float32, device='cuda')              # value targets
+    n = s.shape[0]
+    trainer = GNNTrainer(model, max_batch=BATCH_SIZE)
+    for epoch in range(NUM_EPOCH):
+        lr = LEARNING_RATE * lr_lambda(epoch)                                      # LambdaLR, stepped once per epoch (:98)
+        perm = torch.randperm(n, device='cuda')                                    # DataLoader(shuffle=True), last batch kept
+        epoch_policy_loss = torch.zeros((), device='cuda')
+        epoch_value_loss = torch.zeros((), device='cuda')
+        for i in range(0, n, BATCH_SIZE):
+            idx = perm[i:i + BATCH_SIZE]
+            pl, vl = trainer.step(s[idx], p[idx], v[idx], lr=lr)
+            epoch_policy_loss += pl
+            epoch_value_loss += vl
+        print(f"\rEpoch {epoch + 1}/{NUM_EPOCH} | Policy Loss: {float(epoch_policy_loss):.4f} | Value Loss: {float(epoch_value_loss):.4f}", end='')
+    print('')
+    torch.save(model.state_dict(), PV_NETWORK_PATH + 'latest.pth')
+
+
+if __name__ == '__main__':
+    train_network()

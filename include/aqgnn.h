@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define AQG_MAX_LEGAL 136 /* >= 5 pawn moves + 128 wall placements */
-#define AQG_ABI_VERSION 2
+#define AQG_ABI_VERSION 3
 
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
@@ -156,6 +156,35 @@ int aqg_engine_move(const aqg_engine* e_host, const double* uniforms, void* stre
 int aqg_engine_search(const aqg_engine* e_host, const uint8_t* root_states72, void* stream);
 /* Read back the root's children after a search: visits [G,AQG_MAX_LEGAL] i32, actions [G,AQG_MAX_LEGAL] u8, count [G]. */
 int aqg_engine_root_visits(const aqg_engine* e_host, int32_t* visits, uint8_t* actions, int32_t* count, void* stream);
+
+/* ------------------------------------------------------------------ training step (train_network.py:68-95 on the GNN) */
+
+/* One optimisation step on a batch of positions: forward, the reference's losses (CrossEntropyLoss applied to the
+ * already-softmaxed policy with probability targets train_network.py:54,85 + MSELoss on the tanh value :55,86),
+ * backward, and -- if do_update -- torch.optim.Adam's update (:56,:90-92).  fp32 throughout.  The 14 parameter tensors
+ * are the state_dict tensors themselves in their PyTorch layouts and in the key order of KEYS in INTEGRATION.md; grads,
+ * adam_m, adam_v have the same shapes.  All memory is the caller's (device pointers); nothing allocates or synchronises.
+ * B = batch, V = board_size^2, A = policy size. */
+typedef struct aqg_train {
+    int32_t board_size, batch, policy_size;
+    int32_t step;                 /* Adam step count of THIS update, >= 1 */
+    float lr, beta1, beta2, eps;  /* 1e-3 * LambdaLR factor (train_network.py:56-66), 0.9, 0.999, 1e-8 */
+    float* params[14]; float* grads[14]; float* adam_m[14]; float* adam_v[14];
+    /* workspace */
+    float* x0;                    /* [B*V, 6]   node features */
+    int32_t* ell_idx; float* ell_w;   /* [B*V, 5]  normalised adjacency, ELL: self, U, D, L, R (index -1 = no edge) */
+    float* zbuf;                  /* [B*V, 128] scratch */
+    float* h1; float* h2; float* h3;  /* [B*V, 128] post-ReLU activations of the three GCN layers */
+    float* dh;                    /* [B*V, 128] scratch */
+    float* g; float* dg;          /* [B, 128]   pooled features and their gradient */
+    float* hp; float* hv; float* dhp; float* dhv;   /* [B, 64] head hidden layers and gradients */
+    float* lg;                    /* [B, A]     logits; overwritten by d loss / d logits */
+    float* pol;                   /* [B, A]     softmax policy (the network output) */
+    float* vp; float* val;        /* [B]        pre-tanh value (overwritten by its gradient), tanh value */
+    float* loss;                  /* [B, 2]     per-position policy / value loss terms (their means are the two losses) */
+} aqg_train;
+int aqg_gcn_train_step(const aqg_train* t_host, const uint8_t* states72, const float* pi_target, const float* z_target,
+                       int do_update, void* stream);
 
 #ifdef __cplusplus
 }

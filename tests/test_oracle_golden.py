@@ -128,6 +128,19 @@ def test_evaluation_games_match_reference(N):
         assert point == float(g[f"e{i}_point"][0])
 
 
+def test_training_oracle_forward_equals_gnn_oracle():
+    """oracle/train.py (torch fp64, dense adjacency, autograd) restates the same network as oracle/gnn.py."""
+    from oracle import gnn as og, train as ot
+    g = U.golden("walk_9x9.npz")
+    recs = g["states"][::700][:12]
+    p = og.init_params(4)
+    pol, val = ot.TorchGNN(p)(recs)
+    ref = og.forward_states(p, recs)
+    assert np.abs(pol.detach().numpy() - ref["policy"]).max() < 1e-14
+    assert np.abs(val.detach().numpy()[:, 0] - ref["value"]).max() < 1e-14
+    assert [ot.lr_lambda(e) for e in (0, 49, 50, 79, 80, 99)] == [1.0, 1.0, 0.5, 0.5, 0.25, 0.25]   # train_network.py:59-65
+
+
 def test_choice_index_matches_numpy():
     rng = np.random.RandomState(5)
     for _ in range(200):
