@@ -40,7 +40,7 @@ class TrainStruct(_c.Structure):
         + [(n, _f32) for n in ("lr", "beta1", "beta2", "eps")]
         + [(n, _vp * 14) for n in ("params", "grads", "adam_m", "adam_v")]
         + [(n, _vp) for n in ("x0", "ell_idx", "ell_w", "zbuf", "h1", "h2", "h3", "dh", "g", "dg", "hp", "hv", "dhp", "dhv",
-                              "lg", "pol", "vp", "val", "loss")]
+                              "lg", "pol", "vp", "val", "loss", "part")]
     )
 
 

@@ -106,19 +106,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ X, 
     }
 }
 
-// weight gradient: G[a][b] = sum_r A[r][a] * Bm[r][b]     A: [R][Ja], Bm: [R][Kb], G: [Ja][Kb]; fixed summation order
+// weight gradient: G[a][b] = sum_r A[r][a] * Bm[r][b]     A: [R][Ja], Bm: [R][Kb], G: [Ja][Kb].
+// The row range is cut into gridDim.z slices (the 10,368-row trunk gradients would otherwise run on 16 workgroups);
+// slice z writes its partial sum to G + z * Ja * Kb and reduce_partials_kernel adds the slices in fixed order.
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A, int Ja, const float* __restrict__ Bm, int Kb, int R,
-                                                    float* __restrict__ G) {
+                                                    int rows_per_slice, float* __restrict__ G) {
     __shared__ float as[32][33], bs[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int a0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int rbeg = blockIdx.z * rows_per_slice, rend = min(R, rbeg + rows_per_slice);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r0 = 0; r0 < R; r0 += 32) {
+    for (int r0 = rbeg; r0 < rend; r0 += 32) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int rr = ty + 8 * i;
-            as[rr][tx] = (r0 + rr < R && a0 + tx < Ja) ? A[(size_t)(r0 + rr) * Ja + a0 + tx] : 0.f;
-            bs[rr][tx] = (r0 + rr < R && b0 + tx < Kb) ? Bm[(size_t)(r0 + rr) * Kb + b0 + tx] : 0.f;
+            as[rr][tx] = (r0 + rr < rend && a0 + tx < Ja) ? A[(size_t)(r0 + rr) * Ja + a0 + tx] : 0.f;
+            bs[rr][tx] = (r0 + rr < rend && b0 + tx < Kb) ? Bm[(size_t)(r0 + rr) * Kb + b0 + tx] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -129,28 +132,39 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A,
         }
         __syncthreads();
     }
+    float* Gz = G + (size_t)blockIdx.z * Ja * Kb;
     if (b0 + tx < Kb) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (a0 + ty + 8 * i < Ja) G[(size_t)(a0 + ty + 8 * i) * Kb + b0 + tx] = acc[i];
+            if (a0 + ty + 8 * i < Ja) Gz[(size_t)(a0 + ty + 8 * i) * Kb + b0 + tx] = acc[i];
     }
 }
 
-// out[c] = sum_r A[r][c]    (bias gradients); one workgroup per 32 columns, 8 row lanes, fixed order
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int R, int C, float* __restrict__ out) {
+// out[c] = sum_r A[r][c]    (bias gradients); 32 columns x 8 row lanes per workgroup, gridDim.y row slices
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int R, int C, int rows_per_slice, float* __restrict__ out) {
     __shared__ float part[8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + tx;
+    const int rbeg = blockIdx.y * rows_per_slice, rend = min(R, rbeg + rows_per_slice);
     float s = 0.f;
-    if (c < C) for (int r = ty; r < R; r += 8) s += A[(size_t)r * C + c];
+    if (c < C) for (int r = rbeg + ty; r < rend; r += 8) s += A[(size_t)r * C + c];
     part[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < C) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) t += part[i][tx];
-        out[c] = t;
+        out[(size_t)blockIdx.y * C + c] = t;
     }
+}
+
+// out[i] = sum_z part[z * n + i], slices added in index order (deterministic)
+__global__ void reduce_partials_kernel(const float* __restrict__ part, size_t n, int slices, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < slices; ++z) s += part[(size_t)z * n + i];
+    out[i] = s;
 }
 
 // ELL aggregation, one wavefront per node (2 columns per lane): out[n] = sum_s w[n][s] * Z[idx[n][s]] (+ bias) (relu)
@@ -255,11 +269,33 @@ static void gemm(hipStream_t st, bool relu, bool acc, const float* X, int R, int
     else if (!relu && acc) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, st, X, R, S, W, sc, ss, bias, C, Y);
     else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, X, R, S, W, sc, ss, bias, C, Y);
 }
-static void wgrad(hipStream_t st, const float* A, int Ja, const float* Bm, int Kb, int R, float* G) {
-    hipLaunchKernelGGL(wgrad_kernel, dim3((Ja + 31) / 32, (Kb + 31) / 32), dim3(256), 0, st, A, Ja, Bm, Kb, R, G);
+constexpr int TRAIN_SLICE_ROWS = 256;     // rows per partial sum
+constexpr int TRAIN_MAX_SLICES = 64;      // aqg_train.part holds TRAIN_MAX_SLICES * 128 * 128 floats
+
+static void wgrad(hipStream_t st, float* part, const float* A, int Ja, const float* Bm, int Kb, int R, float* G) {
+    int slices = (R + TRAIN_SLICE_ROWS - 1) / TRAIN_SLICE_ROWS;
+    if (slices > TRAIN_MAX_SLICES) slices = TRAIN_MAX_SLICES;
+    const int rows = ((R + slices - 1) / slices + 31) / 32 * 32;
+    const dim3 grid((Ja + 31) / 32, (Kb + 31) / 32, slices);
+    if (slices == 1) {
+        hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, A, Ja, Bm, Kb, R, rows, G);
+        return;
+    }
+    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, A, Ja, Bm, Kb, R, rows, part);
+    const size_t n = (size_t)Ja * Kb;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)part, n, slices, G);
 }
-static void colsum(hipStream_t st, const float* A, int R, int C, float* out) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 31) / 32), dim3(256), 0, st, A, R, C, out);
+static void colsum(hipStream_t st, float* part, const float* A, int R, int C, float* out) {
+    int slices = (R + TRAIN_SLICE_ROWS - 1) / TRAIN_SLICE_ROWS;
+    if (slices > TRAIN_MAX_SLICES) slices = TRAIN_MAX_SLICES;
+    const int rows = ((R + slices - 1) / slices + 7) / 8 * 8;
+    const dim3 grid((C + 31) / 32, slices);
+    if (slices == 1) {
+        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, A, R, C, rows, out);
+        return;
+    }
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, A, R, C, rows, part);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, (const float*)part, (size_t)C, slices, out);
 }
 
 // parameter order = state_dict order (KEYS in INTEGRATION.md):
@@ -292,19 +328,19 @@ int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, con
     hipLaunchKernelGGL(loss_kernel, dim3(B), dim3(256), 0, st, t.lg, t.pol, t.vp, t.val, pi, z, A, B, t.loss);
     if (int r = check_launch("training forward kernels")) return r;
     // ---- backward: heads
-    wgrad(st, t.lg, A, t.hp, H2, B, G[8]);
-    colsum(st, t.lg, B, A, G[9]);
+    wgrad(st, t.part, t.lg, A, t.hp, H2, B, G[8]);
+    colsum(st, t.part, t.lg, B, A, G[9]);
     gemm(st, false, false, t.lg, B, A, P[8], 1, H2, nullptr, H2, t.dhp);           // dhp = dlogits W_p2
     hipLaunchKernelGGL(relu_mask_kernel, dim3((B * H2 + 255) / 256), dim3(256), 0, st, t.dhp, (const float*)t.hp, (size_t)B * H2);
-    wgrad(st, t.dhp, H2, t.g, TH, B, G[6]);
-    colsum(st, t.dhp, B, H2, G[7]);
+    wgrad(st, t.part, t.dhp, H2, t.g, TH, B, G[6]);
+    colsum(st, t.part, t.dhp, B, H2, G[7]);
     gemm(st, false, false, t.dhp, B, H2, P[6], 1, TH, nullptr, TH, t.dg);           // dg = dhp W_p1
-    wgrad(st, t.vp, 1, t.hv, H2, B, G[12]);
-    colsum(st, t.vp, B, 1, G[13]);
+    wgrad(st, t.part, t.vp, 1, t.hv, H2, B, G[12]);
+    colsum(st, t.part, t.vp, B, 1, G[13]);
     gemm(st, false, false, t.vp, B, 1, P[12], 1, H2, nullptr, H2, t.dhv);
     hipLaunchKernelGGL(relu_mask_kernel, dim3((B * H2 + 255) / 256), dim3(256), 0, st, t.dhv, (const float*)t.hv, (size_t)B * H2);
-    wgrad(st, t.dhv, H2, t.g, TH, B, G[10]);
-    colsum(st, t.dhv, B, H2, G[11]);
+    wgrad(st, t.part, t.dhv, H2, t.g, TH, B, G[10]);
+    colsum(st, t.part, t.dhv, B, H2, G[11]);
     gemm(st, false, true, t.dhv, B, H2, P[10], 1, TH, nullptr, TH, t.dg);           // dg += dhv W_v1
     // ---- backward: trunk
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(B), dim3(128), 0, st, (const float*)t.dg, V, t.dh);
@@ -314,11 +350,11 @@ int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, con
     float* hout[3] = {t.h1, t.h2, t.h3};
     for (int L = 2; L >= 0; --L) {
         hipLaunchKernelGGL(relu_mask_kernel, mg, mb, 0, st, t.dh, (const float*)hout[L], nel);      // dP
-        colsum(st, t.dh, R, TH, G[2 * L + 1]);
+        colsum(st, t.part, t.dh, R, TH, G[2 * L + 1]);
         hipLaunchKernelGGL(agg_kernel<false>, ag, ab, 0, st, (const float*)t.dh, R, (const int32_t*)t.ell_idx, (const float*)t.ell_w,
                            (const float*)nullptr, t.zbuf);                                          // dZ = A_hat dP
         const int K = L == 0 ? TF : TH;
-        wgrad(st, t.zbuf, TH, hin[L], K, R, G[2 * L]);
+        wgrad(st, t.part, t.zbuf, TH, hin[L], K, R, G[2 * L]);
         if (L > 0) gemm(st, false, false, t.zbuf, R, TH, P[2 * L], 1, TH, nullptr, TH, t.dh);       // dH_{L-1} = dZ W_L
     }
     if (int r = check_launch("training backward kernels")) return r;

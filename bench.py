@@ -188,6 +188,18 @@ def main():
     _lib.set_option("trunk_variant", 3)
     fwd_ms = time_ms(fwd, 200, warmup=20)             # default variant, after the clocks have settled on this workload
 
+    # ---- next-row leg: train_network.py's optimisation step on the GNN, batch 128 (train_network.py:15)
+    from alphaquoridorgnn_amd.train_network import GNNTrainer, BATCH_SIZE
+    tr_model = GNNNetwork().to(dev)
+    trainer = GNNTrainer(tr_model, max_batch=BATCH_SIZE)
+    tb = boards[:BATCH_SIZE]
+    tpi = torch.softmax(torch.randn((BATCH_SIZE, 209), device=dev), dim=1)
+    tz = torch.randint(-1, 2, (BATCH_SIZE,), device=dev).float()
+    train_ms = time_ms(lambda: trainer.step(tb, tpi, tz), 50, warmup=5)
+    train_leg = {"workload": "train_network.py step on the GNN: forward + CE(softmaxed policy) + MSE + backward + Adam, fp32, batch 128",
+                 "ms_per_step": train_ms, "positions_per_s": BATCH_SIZE / (train_ms * 1e-3)}
+    del trainer, tr_model
+
     large = None
     if world == 1 and args.large_games > 0:
         del eng
@@ -252,6 +264,7 @@ def main():
                                  "inside the MCTS are ~2,000 boards = 4 per CU, so avg_launch_us carries the wave-quantisation tail; "
                                  "gnn_forward.trunk_variants is the same kernel at 4,096 boards per launch"},
         }
+        out["train_step"] = train_leg
         if large is not None:
             out["large_batch"] = large
         if world == 1 and not args.no_cpu_baseline:
