@@ -469,6 +469,23 @@ def test_train_network_end_to_end(dev, tmp_path, monkeypatch):
     assert all(torch.isfinite(v).all() for v in new.values())
 
 
+def test_train_cycle_one_iteration(dev, tmp_path, monkeypatch):
+    """train_cycle.py:22-41 end to end in a scratch directory: create_network -> self_play -> train_network ->
+    evaluate_network, every stage on the GPU path, files in the reference's places."""
+    import os
+    from alphaquoridorgnn_amd import train_cycle as tc, self_play as sp, train_network as tn, evaluate_network as en, pv_mcts
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(pv_mcts, "PV_EVALUATE_COUNT", 6)
+    monkeypatch.setattr(sp, "SP_GAME_COUNT", 5)
+    monkeypatch.setattr(tn, "NUM_EPOCH", 2)
+    monkeypatch.setattr(en, "EN_GAME_COUNT", 4)
+    promoted = tc.train_cycle(num_cycles=1)
+    assert len(promoted) == 1 and isinstance(promoted[0], bool)
+    from alphaquoridorgnn_amd.constants import PV_NETWORK_PATH
+    assert os.path.exists(PV_NETWORK_PATH + "best.pth") and os.path.exists(PV_NETWORK_PATH + "latest.pth")
+    assert len(list((tmp_path / "data").glob("*.history"))) == 1
+
+
 # ------------------------------------------------------------------ drop-in surface (reference-shaped calls)
 def test_dropin_surface_play_and_policy(dev, tmp_path, monkeypatch):
     """The reference's call surface end to end on the GPU: pv_mcts_policy / pv_mcts_action on a State, self_play.play()
