@@ -9,7 +9,8 @@ Added (absent from the reference): `forward_states(states72)` -- the 
 self-play engine uses -- and `GNNNetwork`, the BaseNetwork-style wrapper (BaseNetwork.py:9-54) giving
 `predict / prep_for_inference / preprocess_input / name`.
 
-All arithmetic runs in libaqgnn_hip.so (fp32, f32-input MFMA); there is no torch/CPU forward in this file.
+All arithmetic runs in libaqgnn_hip.so (fp32 data; fp16-split or f32-input MFMA, see csrc/gcn_forward.hip); there is no
+torch/CPU forward in this file.
 """
 import ctypes
 import math

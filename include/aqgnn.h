@@ -87,7 +87,8 @@ int aqg_gcn_pack_weights_host(int board_size, const float* const* tensors_host, 
 /* GraphPolicyValueNetwork.forward  pv_network_gnn.py:53-64 on B boards given as state72 records: node
  * features = pv_network_cnn.py:88-114 read as [V,6]; graph = wall-cut 4-neighbour grid;
  * 3 x (GCNConv + ReLU) -> global_mean_pool -> heads.  f32 data and accumulation throughout; the two 128x128
- * contractions run on the matrix cores either as exact f32-input MFMA or as a 6-term bf16 split (default, same tolerance).
+ * contractions and the neighbourhood aggregation run on the matrix cores as an fp16 hi/lo split with f32 accumulation
+ * (default, fp32-equivalent) or as exact f32-input MFMA + VALU aggregation (trunk_variant 0/1, same tolerance).
  *   pooled    [B,128]  workspace/out: mean-pooled trunk features
  *   logits    [B,A]    pre-softmax policy (may be NULL)
  *   policy    [B,A]    Softmax output == module output (may be NULL)
