@@ -9,7 +9,7 @@ from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
 from tools.microbench import synth_states
 
 B = int(os.environ.get("AQG_B", "65536"))
-variant = int(os.environ.get("AQG_VARIANT", "0"))
+variant = int(os.environ.get("AQG_VARIANT", "3"))
 iters = int(os.environ.get("AQG_ITERS", "5"))
 dev = _lib.require_gpu("cuda:0")
 lib = _lib.load()
