@@ -29,7 +29,7 @@ int engine_reset(const aqg_engine& e, hipStream_t st);
 int engine_move(const aqg_engine& e, const double* uniforms, hipStream_t st);
 int engine_search(const aqg_engine& e, const uint8_t* roots72, hipStream_t st);
 int engine_root_visits(const aqg_engine& e, int32_t* visits, uint8_t* actions, int32_t* count, hipStream_t st);
-int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, const float* z, int do_update, hipStream_t st);
+int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, const float* z, int mode, hipStream_t st);
 }  // namespace aqg
 
 using namespace aqg;
@@ -113,13 +113,14 @@ int aqg_engine_root_visits(const aqg_engine* e, int32_t* visits, uint8_t* action
     return engine_root_visits(*e, visits, actions, count, (hipStream_t)stream);
 }
 
-int aqg_gcn_train_step(const aqg_train* t, const uint8_t* states72, const float* pi_target, const float* z_target, int do_update,
+int aqg_gcn_train_step(const aqg_train* t, const uint8_t* states72, const float* pi_target, const float* z_target, int mode,
                        void* stream) {
-    if (!t || !states72 || !pi_target || !z_target) return fail("aqg_gcn_train_step: null argument");
+    if (!t || mode < 0 || mode > 2) return fail("aqg_gcn_train_step: bad argument");
+    if (mode != 2 && (!states72 || !pi_target || !z_target)) return fail("aqg_gcn_train_step: null argument");
     for (int i = 0; i < 14; ++i)
-        if (!t->params[i] || !t->grads[i] || (do_update && (!t->adam_m[i] || !t->adam_v[i]))) return fail("aqg_gcn_train_step: null parameter tensor");
-    if (do_update && t->step < 1) return fail("aqg_gcn_train_step: step must be >= 1");
-    return train_step(*t, states72, pi_target, z_target, do_update, (hipStream_t)stream);
+        if (!t->params[i] || !t->grads[i] || (mode >= 1 && (!t->adam_m[i] || !t->adam_v[i]))) return fail("aqg_gcn_train_step: null parameter tensor");
+    if (mode >= 1 && t->step < 1) return fail("aqg_gcn_train_step: step must be >= 1");
+    return train_step(*t, states72, pi_target, z_target, mode, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -301,14 +301,16 @@ static void colsum(hipStream_t st, float* part, const float* A, int R, int C, fl
 // parameter order = state_dict order (KEYS in INTEGRATION.md):
 //  0 gcn0.w [H,F]  1 gcn0.b  2 gcn1.w [H,H]  3 gcn1.b  4 gcn2.w  5 gcn2.b
 //  6 pol0.w [H/2,H]  7 pol0.b  8 pol2.w [A,H/2]  9 pol2.b  10 val0.w [H/2,H]  11 val0.b  12 val2.w [1,H/2]  13 val2.b
-int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, const float* z, int do_update, hipStream_t st) {
+int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, const float* z, int mode, hipStream_t st) {
     const int N = t.board_size, B = t.batch, A = t.policy_size;
+    const int do_update = mode >= 1, do_grads = mode != 2;     // 0 gradients only, 1 gradients + Adam, 2 Adam only
     if (!(N == 3 || N == 5 || N == 7 || N == 9)) return fail("board_size must be 3, 5, 7 or 9");
     if (A != N * N + 2 * (N - 1) * (N - 1) || A > 256) return fail("policy_size does not match the board");
-    if (B <= 0) return 0;
+    if (B <= 0 && mode != 2) return 0;
     const int V = N * N, R = B * V, H2 = TH / 2;
     float* const* P = t.params;
     float* const* G = t.grads;
+    if (do_grads) {
     // ---- forward
 #define CALL_PREP(n) hipLaunchKernelGGL(train_prep_kernel<n>, dim3((R + 255) / 256), dim3(256), 0, st, states72, B, t.x0, t.ell_idx, t.ell_w)
     switch (N) { case 3: CALL_PREP(3); break; case 5: CALL_PREP(5); break; case 7: CALL_PREP(7); break; default: CALL_PREP(9); break; }
@@ -358,6 +360,7 @@ int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, con
         if (L > 0) gemm(st, false, false, t.zbuf, R, TH, P[2 * L], 1, TH, nullptr, TH, t.dh);       // dH_{L-1} = dZ W_L
     }
     if (int r = check_launch("training backward kernels")) return r;
+    }
     // ---- Adam
     if (do_update) {
         const double bc1 = 1.0 - pow((double)t.beta1, (double)t.step), bc2 = 1.0 - pow((double)t.beta2, (double)t.step);

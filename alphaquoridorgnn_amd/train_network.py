@@ -50,7 +50,12 @@ class GNNTrainer:
         for p in self.params:
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise ValueError("training needs contiguous float32 parameters")
-        self.grads = [torch.zeros_like(p) for p in self.params]
+        # all 14 gradient tensors are views of ONE flat buffer: the data-parallel exchange is a single all-reduce
+        self.flat_grads = torch.zeros((sum(p.numel() for p in self.params),), dtype=torch.float32, device=self.dev)
+        self.grads, off = [], 0
+        for p in self.params:
+            self.grads.append(self.flat_grads[off:off + p.numel()].view_as(p))
+            off += p.numel()
         self.adam_m = [torch.zeros_like(p) for p in self.params]
         self.adam_v = [torch.zeros_like(p) for p in self.params]
         self.N = model.board_size
@@ -79,23 +84,48 @@ class GNNTrainer:
         for name, x in w.items():
             setattr(t, name, x.data_ptr())
 
-    def step(self, states72, pi_target, z_target, lr=LEARNING_RATE, update=True):
+    def _call(self, states72, pi_target, z_target, mode):
+        _lib.check(self.lib.aqg_gcn_train_step(ctypes.byref(self.t), _lib.ptr(states72), _lib.ptr(pi_target), _lib.ptr(z_target),
+                                               mode, _lib.stream_ptr(self.dev)), "aqg_gcn_train_step")
+
+    def step(self, states72, pi_target, z_target, lr=LEARNING_RATE, update=True, group=None):
         """One optimisation step.  states72 uint8 [B,72], pi_target float32 [B,A], z_target float32 [B] (device tensors).
-        Returns (policy_loss, value_loss) as 0-dim device tensors -- no host synchronisation."""
+        Returns (policy_loss, value_loss) as 0-dim device tensors -- no host synchronisation.
+
+        Data parallel (torch.distributed initialised, world > 1): every rank passes ITS shard of the global batch; the
+        local mean-loss gradients are weighted by B_local / B_global, summed with ONE all-reduce of the flat gradient buffer
+        (RCCL over xGMI with backend nccl) and applied by every rank, so all replicas take the step a single process would
+        take on the whole batch (up to fp32 summation order)."""
+        import torch.distributed as dist
         B = int(states72.shape[0])
         if B > self.max_batch:
             raise ValueError("batch larger than the trainer's workspace")
         states72 = states72.to(self.dev, torch.uint8).contiguous()
         pi_target = pi_target.to(self.dev, torch.float32).contiguous()
         z_target = z_target.to(self.dev, torch.float32).contiguous()
+        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         if update:
             self.step_count += 1
         self.t.batch, self.t.step, self.t.lr = B, max(self.step_count, 1), float(lr)
-        _lib.check(self.lib.aqg_gcn_train_step(ctypes.byref(self.t), _lib.ptr(states72), _lib.ptr(pi_target), _lib.ptr(z_target),
-                                               1 if update else 0, _lib.stream_ptr(self.dev)), "aqg_gcn_train_step")
+        if world == 1:
+            self._call(states72, pi_target, z_target, 1 if update else 0)
+            loss = self.ws["loss"][:B].mean(dim=0) if B else torch.zeros((2,), device=self.dev)
+        else:
+            if B:
+                self._call(states72, pi_target, z_target, 0)
+                lsum = self.ws["loss"][:B].sum(dim=0)
+            else:                                                  # a rank may hold no position of a ragged last batch
+                self.flat_grads.zero_()
+                lsum = torch.zeros((2,), device=self.dev)
+            tot = torch.cat([lsum, torch.tensor([float(B)], device=self.dev)])
+            dist.all_reduce(tot, group=group)                      # global loss sums and global batch size
+            self.flat_grads.mul_(float(B) / tot[2])                # local mean-loss gradient -> its share of the global mean
+            dist.all_reduce(self.flat_grads, group=group)
+            if update:
+                self._call(states72, pi_target, z_target, 2)
+            loss = tot[:2] / tot[2]
         if update:
             self.model.invalidate_packed()
-        loss = self.ws["loss"][:B].mean(dim=0)
         return loss[0], loss[1]
 
     def outputs(self, B):
@@ -104,7 +134,11 @@ class GNNTrainer:
 
 
 def train_network():
-    """train_network.py:26-107 on the GNN: best.pth -> NUM_EPOCH epochs over the newest .history -> latest.pth."""
+    """train_network.py:26-107 on the GNN: best.pth -> NUM_EPOCH epochs over the newest .history -> latest.pth.
+    With torch.distributed initialised the positions of every batch are dealt out over the ranks (same shuffle on all
+    ranks, one gradient all-reduce per step, see GNNTrainer.step) and rank 0 writes latest.pth."""
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
     model = GNNNetwork()
     model.load_state_dict(torch.load(PV_NETWORK_PATH + 'best.pth', map_location='cuda', weights_only=True))
     model = model.to('cuda')
@@ -118,16 +152,20 @@ def train_network():
     for epoch in range(NUM_EPOCH):
         lr = LEARNING_RATE * lr_lambda(epoch)                                      # LambdaLR, stepped once per epoch (:98)
         perm = torch.randperm(n, device='cuda')                                    # DataLoader(shuffle=True), last batch kept
+        if world > 1:
+            dist.broadcast(perm, src=0)
         epoch_policy_loss = torch.zeros((), device='cuda')
         epoch_value_loss = torch.zeros((), device='cuda')
         for i in range(0, n, BATCH_SIZE):
-            idx = perm[i:i + BATCH_SIZE]
+            idx = perm[i:i + BATCH_SIZE][rank::world]
             pl, vl = trainer.step(s[idx], p[idx], v[idx], lr=lr)
             epoch_policy_loss += pl
             epoch_value_loss += vl
-        print(f"\rEpoch {epoch + 1}/{NUM_EPOCH} | Policy Loss: {float(epoch_policy_loss):.4f} | Value Loss: {float(epoch_value_loss):.4f}", end='')
-    print('')
-    torch.save(model.state_dict(), PV_NETWORK_PATH + 'latest.pth')
+        if rank == 0:
+            print(f"\rEpoch {epoch + 1}/{NUM_EPOCH} | Policy Loss: {float(epoch_policy_loss):.4f} | Value Loss: {float(epoch_value_loss):.4f}", end='')
+    if rank == 0:
+        print('')
+        torch.save(model.state_dict(), PV_NETWORK_PATH + 'latest.pth')
 
 
 if __name__ == '__main__':

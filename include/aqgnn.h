@@ -162,7 +162,9 @@ int aqg_engine_root_visits(const aqg_engine* e_host, int32_t* visits, uint8_t* a
 
 /* One optimisation step on a batch of positions: forward, the reference's losses (CrossEntropyLoss applied to the
  * already-softmaxed policy with probability targets train_network.py:54,85 + MSELoss on the tanh value :55,86),
- * backward, and -- if do_update -- torch.optim.Adam's update (:56,:90-92).  fp32 throughout.  The 14 parameter tensors
+ * backward, and torch.optim.Adam's update (:56,:90-92).  fp32 throughout.  mode 0 = gradients only (into grads),
+ * 1 = gradients + update, 2 = update only from whatever grads holds -- data-parallel training computes local gradients
+ * (mode 0), all-reduces them over RCCL, and applies them (mode 2).  The 14 parameter tensors
  * are the state_dict tensors themselves in their PyTorch layouts and in the key order of KEYS in INTEGRATION.md; grads,
  * adam_m, adam_v have the same shapes.  All memory is the caller's (device pointers); nothing allocates or synchronises.
  * B = batch, V = board_size^2, A = policy size. */
@@ -186,7 +188,7 @@ typedef struct aqg_train {
     float* part;                  /* [64 * 128 * 128] partial sums of the row-sliced gradient reductions */
 } aqg_train;
 int aqg_gcn_train_step(const aqg_train* t_host, const uint8_t* states72, const float* pi_target, const float* z_target,
-                       int do_update, void* stream);
+                       int mode, void* stream);
 
 #ifdef __cplusplus
 }

@@ -4,11 +4,16 @@
 Bars: bit-exact for legal masks / ordered lists / transitions / MCTS visit counts / self-play histories;
 fp32 GNN within atol 1e-5 + rtol 1e-4 of the fp64 oracle on pre-softmax logits and pre-tanh value
 (PARITY UNPINNED against PyG itself -- see oracle/gnn.py)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 from tests import _util as U
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -447,6 +452,64 @@ def test_train_adam_steps_vs_torch(dev):
     np.testing.assert_allclose(pol.cpu().numpy(), chk["policy"], atol=2e-6, rtol=1e-3)
 
 
+_DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["AQG_REPO"])
+import numpy as np, torch, torch.distributed as dist
+from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+from alphaquoridorgnn_amd.train_network import GNNTrainer
+from oracle import gnn as og
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["AQG_PORT"], rank=rank, world_size=2)
+d = np.load(os.environ["AQG_DATA"])
+m = GNNNetwork(); m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in og.init_params(8).items()}); m = m.to("cuda")
+tr = GNNTrainer(m, max_batch=32)
+losses = []
+for i in range(3):
+    sl = slice(rank, None, 2) if i < 2 else (slice(0, None) if rank == 0 else slice(0, 0))   # step 2: rank 1 holds nothing
+    pl, vl = tr.step(torch.from_numpy(d[f"s{i}"][sl]), torch.from_numpy(d[f"p{i}"][sl]), torch.from_numpy(d[f"z{i}"][sl]))
+    losses.append([float(pl), float(vl)])
+sd = m.state_dict()
+np.savez(os.environ["AQG_OUT"] + f".{rank}.npz", losses=np.asarray(losses), **{k: sd[k].cpu().numpy() for k in og.KEYS})
+dist.destroy_process_group()
+'''
+
+
+def test_train_data_parallel_equals_single_process(dev, tmp_path):
+    """Data-parallel training step (GNNTrainer.step under torch.distributed): two ranks, each with its share of every
+    batch (incl. a ragged batch in which one rank holds nothing), one gradient all-reduce per step == the single-process
+    step on the whole batch.  gloo on one GPU here (RCCL needs one GPU per rank); the exchange code path is the same."""
+    import subprocess
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+    from alphaquoridorgnn_amd.train_network import GNNTrainer
+    from oracle import gnn as og
+    batches = [_train_batch(32, 30 + i) for i in range(3)]
+    data = {}
+    for i, (r, p, z) in enumerate(batches):
+        data[f"s{i}"], data[f"p{i}"], data[f"z{i}"] = r, p, z
+    np.savez(tmp_path / "data.npz", **data)
+    (tmp_path / "worker.py").write_text(_DP_WORKER)
+    env = dict(os.environ, AQG_REPO=REPO, AQG_PORT=str(29600 + os.getpid() % 300), AQG_DATA=str(tmp_path / "data.npz"),
+               AQG_OUT=str(tmp_path / "out"))
+    procs = [subprocess.Popen([sys.executable, str(tmp_path / "worker.py")], env=dict(env, RANK=str(r))) for r in range(2)]
+    assert all(p.wait(timeout=300) == 0 for p in procs)
+    m = GNNNetwork(); m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in og.init_params(8).items()}); m = m.to(dev)
+    tr = GNNTrainer(m, max_batch=32)
+    ref_losses = []
+    for r, p, z in batches:
+        pl, vl = tr.step(torch.from_numpy(r), torch.from_numpy(p), torch.from_numpy(z))
+        ref_losses.append([float(pl), float(vl)])
+    sd = m.state_dict()
+    outs = [np.load(str(tmp_path / "out") + f".{r}.npz") for r in range(2)]
+    for k in og.KEYS:
+        assert np.array_equal(outs[0][k], outs[1][k]), k                       # replicas stay identical
+        d = np.abs(outs[0][k].astype(np.float64) - sd[k].cpu().numpy().astype(np.float64))
+        assert d.max() <= 0.25 * 1e-3, k                                        # Adam is ill-conditioned where |g| ~ eps ...
+        assert np.quantile(d, 0.99) <= 1e-5, (k, float(np.quantile(d, 0.99)))   # ... everywhere else the steps coincide
+    np.testing.assert_allclose(outs[0]["losses"], np.asarray(ref_losses), rtol=1e-5, atol=1e-7)
+    assert np.array_equal(outs[0]["losses"], outs[1]["losses"])
+
+
 def test_train_network_end_to_end(dev, tmp_path, monkeypatch):
     """train_network() on a .history written by this build's self_play: best.pth -> latest.pth, loss goes down."""
     from alphaquoridorgnn_amd import train_network as tn, self_play, pv_mcts
@@ -472,7 +535,6 @@ def test_train_network_end_to_end(dev, tmp_path, monkeypatch):
 def test_train_cycle_one_iteration(dev, tmp_path, monkeypatch):
     """train_cycle.py:22-41 end to end in a scratch directory: create_network -> self_play -> train_network ->
     evaluate_network, every stage on the GPU path, files in the reference's places."""
-    import os
     from alphaquoridorgnn_amd import train_cycle as tc, self_play as sp, train_network as tn, evaluate_network as en, pv_mcts
     monkeypatch.chdir(tmp_path)
     monkeypatch.setattr(pv_mcts, "PV_EVALUATE_COUNT", 6)
