@@ -695,6 +695,11 @@ __device__ __forceinline__ void stripe_matmul_mm(const TrunkSmemM& sm, const u32
 template <int JT>
 __device__ __forceinline__ void adj_matmul(const TrunkSmemM& sm, const f32x4 (&acc)[6][JT], int lane, f32x4 (&out)[6][JT]) {
     const int q = lane >> 4;
+    // all ten adjacency fragments are requested first: their LDS latency hides under the split arithmetic below (requested
+    // one by one next to their MFMAs, each cost a full lgkmcnt(0) round trip)
+    u32x4 af[AF_BLOCKS];
+#pragma unroll
+    for (int blk = 0; blk < AF_BLOCKS; ++blk) af[blk] = *reinterpret_cast<const u32x4*>(&sm.AF[blk][lane][0]);
     u32x4 zh[3][JT], zl[3][JT];
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
@@ -712,16 +717,17 @@ __device__ __forceinline__ void adj_matmul(const TrunkSmemM& sm, const f32x4 (&a
     for (int nt = 0; nt < 6; ++nt)
 #pragma unroll
         for (int j = 0; j < JT; ++j) out[nt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // two passes (lo term, then hi term) over the blocks in an order that never puts two MFMAs of one accumulator back to
+    // back: node tiles 0,1,2,3,4,5 then 1,2,3,4
+    constexpr int ORDER[AF_BLOCKS] = {0, 1, 3, 5, 7, 9, 2, 4, 6, 8};
 #pragma unroll
-    for (int blk = 0; blk < AF_BLOCKS; ++blk) {
-        const int kb = af_kb(blk), nt = af_nt(blk);
-        const u32x4 af = *reinterpret_cast<const u32x4*>(&sm.AF[blk][lane][0]);
+    for (int term = 0; term < 2; ++term)
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
-            out[nt][j] = mfma_f16(zl[kb][j], af, out[nt][j]);
-            out[nt][j] = mfma_f16(zh[kb][j], af, out[nt][j]);
+        for (int i = 0; i < AF_BLOCKS; ++i) {
+            const int blk = ORDER[i], kb = af_kb(blk), nt = af_nt(blk);
+#pragma unroll
+            for (int j = 0; j < JT; ++j) out[nt][j] = mfma_f16(term == 0 ? zl[kb][j] : zh[kb][j], af[blk], out[nt][j]);
         }
-    }
 }
 
 // aggregation part 2: H' = relu(dinv_n * Y + b) -> split planes (lane = node, 4 consecutive features), or the mean pool
@@ -814,11 +820,10 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     AQG_STAMP_DECL
     while (b < B) {
         AQG_STAMP_AT(7)
-        // loads first (they land under the setup); vmcnt retires in order, so the small layer-1 fragment goes ahead
+        // the small layer-1 weight fragment goes out first (lands under the setup)
         u32x4 w1f[JT];
 #pragma unroll
         for (int j = 0; j < JT; ++j) w1f[j] = load_frag16(rs, lane * 16, (int)(PackedLayout::WH1 * sizeof(float)) + (wave * JT + j) * (64 * 16));
-        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
         // ---- setup.  The record becomes wave-uniform scalars (the wall masks by ballot over the 64 wall bytes), the
         //      open-edge bitboards are computed once per wave on the scalar unit, lanes only extract their bits.
@@ -901,6 +906,9 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         }
         AQG_STAMP_AT(8)
         adj_matmul<JT>(sm, acc, lane, out);
+        __builtin_amdgcn_sched_barrier(0);
+        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights: land under the plane stores + barrier
+        __builtin_amdgcn_sched_barrier(0);
         AQG_STAMP_AT(9)
         adj_store<JT, false>(sm, out, 0, wave, lane, nullptr);
         AQG_STAMP_AT(10)
@@ -909,12 +917,13 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         // ---- layer 2
         stripe_matmul_mm<JT>(sm, Bf, lane, acc);
         AQG_STAMP_AT(2)
-        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH3, wave, lane);             // lands under the aggregation
-        uint32_t nrec0 = 0, nrec1 = 0;                                      // next board's record rides behind it (vmcnt retires
-        if (bn < B) fetch_record(bn, nrec0, nrec1);                         // in order: it is complete once layer 3 has its weights)
-        __builtin_amdgcn_sched_barrier(0);
         AQG_STAMP_AT(11)
         adj_matmul<JT>(sm, acc, lane, out);
+        __builtin_amdgcn_sched_barrier(0);
+        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH3, wave, lane);             // lands under the barrier + plane stores (its 32
+        uint32_t nrec0 = 0, nrec1 = 0;                                      // registers are needed by the adjacency fragments
+        if (bn < B) fetch_record(bn, nrec0, nrec1);                         // before); the next board's record rides behind it
+        __builtin_amdgcn_sched_barrier(0);
         AQG_STAMP_AT(12)
         __syncthreads();                                                    // every wave is done reading the planes
         AQG_STAMP_AT(13)
