@@ -556,9 +556,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int PROW = 272;                    // plane row stride in bytes: 128 fp16 + 16 B pad (17 slots of 16 B: odd ->
-                                             // the 16-lane ds_read_b128 groups of an A fragment hit distinct bank slots)
-constexpr int PPLANE = 81 * PROW + 48;       // plane stride (22,080 B)
+constexpr int PROW = 256;                    // plane row = 128 fp16, unpadded: 16 slots of 16 B, XOR-swizzled by the row
+constexpr int PPLANE = 81 * PROW;            // plane stride (20,736 B)
+// Byte offset of 16-byte slot `slot` (0..15) of plane row `row`: slot ^ (row & 15).  The 16 rows an A-fragment
+// ds_read_b128 lane group touches (same slot, rows 16m + 0..15) land on 16 distinct bank slots, and so do the 16 rows of
+// one 8-byte store group -- what the 272-byte padded rows did before, without the 2.6 KB of padding per board.
+__device__ __forceinline__ int plane_off(int row, int slot) { return row * PROW + ((slot ^ (row & 15)) << 4); }
 
 __device__ __forceinline__ unsigned int cvt_pk_f16(float a, float b) {            // RNE, low half = a
     return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){a, b}, f16x2));
@@ -607,9 +610,8 @@ struct alignas(16) TrunkSmemM {
     alignas(16) unsigned int AF[AF_BLOCKS][64][4];     // (A + I) B fragments of this board (fp16 0 / 1)
     alignas(16) unsigned int X0[96][4];                // node features as 8 fp16 (6 used); rows 81..95 stay zero
     alignas(16) float dinv[96];                        // deg^-1/2 per node; entries 81..95 stay zero
-    alignas(16) float bias[3][HID];
 };
-static_assert(2 * sizeof(TrunkSmemM) <= 160 * 1024, "two workgroups per CU");
+static_assert(3 * sizeof(TrunkSmemM) <= 160 * 1024, "three 4-wave workgroups per CU");
 
 __device__ __forceinline__ float row16_sum(float x) {     // sum over the 16 lanes of a DPP row, result in every lane
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));   // row_ror:8
@@ -662,7 +664,7 @@ __device__ __forceinline__ void stripe_matmul_mm(const TrunkSmemM& sm, const u32
     auto frag_off = [&](int step) -> int {                  // step = m*4 + kb
         const int m = step >> 2, kb = step & 3;
         const int row = (m < 5) ? 16 * m + c : 80;
-        return row * PROW + 64 * kb + 16 * q;
+        return plane_off(row, 4 * kb + q);
     };
     {
         const int o = frag_off(0);
@@ -700,45 +702,51 @@ __device__ __forceinline__ void adj_matmul(const TrunkSmemM& sm, const f32x4 (&a
     u32x4 af[AF_BLOCKS];
 #pragma unroll
     for (int blk = 0; blk < AF_BLOCKS; ++blk) af[blk] = *reinterpret_cast<const u32x4*>(&sm.AF[blk][lane][0]);
-    u32x4 zh[3][JT], zl[3][JT];
+    f32x4 d4[6];
 #pragma unroll
-    for (int m = 0; m < 6; ++m) {
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(&sm.dinv[16 * m + 4 * q]);   // 0 beyond node 80: clears tile 5's duplicate rows
+    for (int m = 0; m < 6; ++m) d4[m] = *reinterpret_cast<const f32x4*>(&sm.dinv[16 * m + 4 * q]);   // 0 beyond node 80: clears tile 5's duplicate rows
+    // one feature tile at a time (its accumulators die as its fragments are built: the 4-wave form fits 168 registers)
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
-            const f32x4 z = acc[m][j] * d4;
+    for (int j = 0; j < JT; ++j) {
+        u32x4 zh[3], zl[3];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            const f32x4 z = acc[m][j] * d4[m];
             const unsigned int h01 = cvt_pk_f16(z[0], z[1]), h23 = cvt_pk_f16(z[2], z[3]);
             const f32x4 r = z - f16_pairs_to_f32(h01, h23);
-            zh[m >> 1][j][2 * (m & 1)] = h01; zh[m >> 1][j][2 * (m & 1) + 1] = h23;
-            zl[m >> 1][j][2 * (m & 1)] = cvt_pk_f16(r[0], r[1]); zl[m >> 1][j][2 * (m & 1) + 1] = cvt_pk_f16(r[2], r[3]);
+            zh[m >> 1][2 * (m & 1)] = h01; zh[m >> 1][2 * (m & 1) + 1] = h23;
+            zl[m >> 1][2 * (m & 1)] = cvt_pk_f16(r[0], r[1]); zl[m >> 1][2 * (m & 1) + 1] = cvt_pk_f16(r[2], r[3]);
         }
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) out[nt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // two passes (lo term, then hi term) over the blocks in an order that never puts two MFMAs of one accumulator
+        // back to back: node tiles 0,1,2,3,4,5 then 1,2,3,4
+        constexpr int ORDER[AF_BLOCKS] = {0, 1, 3, 5, 7, 9, 2, 4, 6, 8};
+#pragma unroll
+        for (int term = 0; term < 2; ++term)
+#pragma unroll
+            for (int i = 0; i < AF_BLOCKS; ++i) {
+                const int blk = ORDER[i], kb = af_kb(blk), nt = af_nt(blk);
+                out[nt][j] = mfma_f16(term == 0 ? zl[kb] : zh[kb], af[blk], out[nt][j]);
+            }
     }
+}
+
+// this lane's 4 bias values per feature tile, straight from the packed buffer (requested before the aggregation MFMAs,
+// consumed after them)
+template <int JT>
+__device__ __forceinline__ void load_bias(f32x4 (&bias4)[JT], __amdgpu_buffer_rsrc_t rs, size_t region, int wave, int lane) {
 #pragma unroll
-    for (int nt = 0; nt < 6; ++nt)
-#pragma unroll
-        for (int j = 0; j < JT; ++j) out[nt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // two passes (lo term, then hi term) over the blocks in an order that never puts two MFMAs of one accumulator back to
-    // back: node tiles 0,1,2,3,4,5 then 1,2,3,4
-    constexpr int ORDER[AF_BLOCKS] = {0, 1, 3, 5, 7, 9, 2, 4, 6, 8};
-#pragma unroll
-    for (int term = 0; term < 2; ++term)
-#pragma unroll
-        for (int i = 0; i < AF_BLOCKS; ++i) {
-            const int blk = ORDER[i], kb = af_kb(blk), nt = af_nt(blk);
-#pragma unroll
-            for (int j = 0; j < JT; ++j) out[nt][j] = mfma_f16(term == 0 ? zl[kb][j] : zh[kb][j], af[blk], out[nt][j]);
-        }
+    for (int j = 0; j < JT; ++j)
+        bias4[j] = __builtin_bit_cast(f32x4, load_frag16(rs, (lane >> 4) * 16, (int)(region * sizeof(float)) + 64 * (JT * wave + j)));
 }
 
 // aggregation part 2: H' = relu(dinv_n * Y + b) -> split planes (lane = node, 4 consecutive features), or the mean pool
 template <int JT, bool LAST>
-__device__ __forceinline__ void adj_store(TrunkSmemM& sm, const f32x4 (&out)[6][JT], int layer, int wave, int lane,
+__device__ __forceinline__ void adj_store(TrunkSmemM& sm, const f32x4 (&out)[6][JT], const f32x4 (&bias4)[JT], int wave, int lane,
                                           float* __restrict__ pooled_out) {
     const int c = lane & 15, q = lane >> 4;
     const int col0 = 16 * JT * wave + 4 * q;
-    f32x4 bias4[JT];
-#pragma unroll
-    for (int j = 0; j < JT; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(&sm.bias[layer][col0 + 16 * j]);
     f32x4 sum[JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) sum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -755,7 +763,7 @@ __device__ __forceinline__ void adj_store(TrunkSmemM& sm, const f32x4 (&out)[6][
             if (LAST) {
                 if (live) sum[j] += v;
             } else {
-                if (live) store_split4(sm, node * PROW + 2 * (col0 + 16 * j), v);
+                if (live) store_split4(sm, plane_off(node, (col0 + 16 * j) >> 3) + ((2 * (col0 + 16 * j)) & 15), v);
             }
         }
     }
@@ -786,7 +794,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     __shared__ TrunkSmemM sm;
     // The two workgroups resident on a CU run identical phase sequences; a start offset for the second-resident ones
     // (phase_delay x 64 cycles) keeps one on the matrix pipe while the other does vector work.
-    if (blockIdx.x >= 256) for (int i = 0; i < phase_delay; ++i) __builtin_amdgcn_s_sleep(1);
+    for (int i = 0; i < (int)(blockIdx.x >> 8) * phase_delay; ++i) __builtin_amdgcn_s_sleep(1);   // 2nd / 3rd resident: 1x / 2x
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, q = lane >> 4;
@@ -806,14 +814,10 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         }
     };
     if (b < B) fetch_record(b, rec0, rec1);
-    // once per workgroup: the padding rows no board ever writes, and the three bias vectors.  No barrier here: the first
-    // reader of any of it sits behind the first board's setup barrier.
+    // once per workgroup: the padding rows no board ever writes.  No barrier here: their first reader sits behind the
+    // first board's setup barrier.
     if (tid < 15 * 4) (&sm.X0[81][0])[tid] = 0u;
     if (tid < 15) sm.dinv[81 + tid] = 0.f;
-    for (int i = tid; i < 3 * HID; i += NTHR) {
-        const int L = i >> 7, k = i & 127;
-        sm.bias[L][k] = pk[(L == 0 ? PackedLayout::B1 : L == 1 ? PackedLayout::B2 : PackedLayout::B3) + k];
-    }
     u32x4 Bf[2][JT][4];
     const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
 
@@ -905,12 +909,14 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
             for (int j = 0; j < JT; ++j) acc[m][j] = mfma_f16(xf, w1f[j], (f32x4){0.f, 0.f, 0.f, 0.f});
         }
         AQG_STAMP_AT(8)
+        f32x4 bias4[JT];
+        load_bias<JT>(bias4, rs, PackedLayout::B1, wave, lane);
         adj_matmul<JT>(sm, acc, lane, out);
         __builtin_amdgcn_sched_barrier(0);
         load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights: land under the plane stores + barrier
         __builtin_amdgcn_sched_barrier(0);
         AQG_STAMP_AT(9)
-        adj_store<JT, false>(sm, out, 0, wave, lane, nullptr);
+        adj_store<JT, false>(sm, out, bias4, wave, lane, nullptr);
         AQG_STAMP_AT(10)
         __syncthreads();
         AQG_STAMP_AT(1)
@@ -918,6 +924,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         stripe_matmul_mm<JT>(sm, Bf, lane, acc);
         AQG_STAMP_AT(2)
         AQG_STAMP_AT(11)
+        load_bias<JT>(bias4, rs, PackedLayout::B2, wave, lane);
         adj_matmul<JT>(sm, acc, lane, out);
         __builtin_amdgcn_sched_barrier(0);
         load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH3, wave, lane);             // lands under the barrier + plane stores (its 32
@@ -927,16 +934,17 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         AQG_STAMP_AT(12)
         __syncthreads();                                                    // every wave is done reading the planes
         AQG_STAMP_AT(13)
-        adj_store<JT, false>(sm, out, 1, wave, lane, nullptr);
+        adj_store<JT, false>(sm, out, bias4, wave, lane, nullptr);
         AQG_STAMP_AT(14)
         __syncthreads();
         AQG_STAMP_AT(3)
         // ---- layer 3 + mean pool
         stripe_matmul_mm<JT>(sm, Bf, lane, acc);
         AQG_STAMP_AT(4)
+        load_bias<JT>(bias4, rs, PackedLayout::B3, wave, lane);
         adj_matmul<JT>(sm, acc, lane, out);
         AQG_STAMP_AT(15)
-        adj_store<JT, true>(sm, out, 2, wave, lane, pooled + (size_t)b * HID);
+        adj_store<JT, true>(sm, out, bias4, wave, lane, pooled + (size_t)b * HID);
         rec0 = nrec0; rec1 = nrec1;
         __syncthreads();                                                    // AF / X0 / dinv / planes are free for the next board
         AQG_STAMP_AT(5)
@@ -1266,8 +1274,9 @@ __global__ __launch_bounds__(256, 2) void gcn_heads_mm_kernel(const float* __res
 
 // Trunk variants (aqg_set_option("trunk_variant", v)):
 //   0 exact f32-input MFMA + VALU gather, weights resident, 1 workgroup/CU      1 the same, 2 workgroups/CU
-//   3 all-MFMA fp16 split trunk, 8 waves per board (16-column stripes, 4 waves per SIMD)  [default]
-//   4 all-MFMA fp16 split trunk, 4 waves per board (32-column stripes, 2 waves per SIMD)
+//   3 all-MFMA fp16 split trunk, form chosen per launch  [default]: 8 waves per board x 2 workgroups/CU below 768 boards,
+//     4 waves per board x 3 workgroups/CU from 768 boards
+//   4 force 4 waves per board x 3/CU      5 force 4 waves per board x 2/CU      6 force 8 waves per board x 2/CU
 // An earlier split-precision kernel kept the VALU gather of variants 0/1 on a 16-bit plane image (bf16 x6 / x3 and
 // fp16 x3 forms).  It was removed: its gather read plane bytes no wave had written for the current board (harmless
 // with benign leftovers, wrong once the LDS held NaN patterns -- tools/cold_launch_check.py poisons the LDS before
@@ -1343,11 +1352,17 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     } else if (g_trunk_variant == 1) {
         int grid = B < 512 ? B : 512;
         hipLaunchKernelGGL((gcn_trunk_boards_kernel<false, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
-    } else if (g_trunk_variant == 4) {
+    } else if (g_trunk_variant == 5) {
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
         hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, B >= 8192 ? g_trunk_phase_delay : 0);
+    } else if (g_trunk_variant == 4 || (g_trunk_variant == 3 && B >= 768)) {
+        // three 4-wave workgroups per CU: more boards in flight per CU; wins from ~768 boards per launch (tools/phase_scan.py)
+        int grid = B < 768 ? B : 768;
+        if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
+        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 3>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, B >= 8192 ? g_trunk_phase_delay / 2 : 0);
     } else {
+        // two 8-wave workgroups per CU: shortest latency per board, best when a launch has at most ~2 boards per CU
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
         hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, B >= 8192 ? g_trunk_phase_delay : 0);

@@ -116,7 +116,7 @@ def test_legal_actions_large_batch_properties(dev):
 
 
 # ------------------------------------------------------------------ K1/K2 GNN forward
-@pytest.mark.parametrize("variant", [0, 1, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5, 6])
 def test_gnn_forward_boards_vs_fp64_oracle(dev, variant):
     from alphaquoridorgnn_amd import _lib
     from oracle import gnn as og
@@ -144,7 +144,7 @@ def test_gnn_forward_boards_vs_fp64_oracle(dev, variant):
     _lib.set_option("trunk_variant", 3)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("variant", [1, 4, 6])
 def test_gnn_forward_scaled_weights(dev, variant):
     """Weights scaled up so activations are O(10): relative tolerance still holds (catches layout slips that
     small random weights could hide)."""

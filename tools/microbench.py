@@ -84,7 +84,7 @@ def main():
                 _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy),
                                                       None, _lib.ptr(value), _lib.stream_ptr(dev)), "full")
             for rnd in range(2):
-                for v in (1, 3, 4):
+                for v in (1, 6, 4):
                     _lib.set_option("trunk_variant", v)
                     t = time_ms(trunk, args.iters)
                     f = time_ms(full, args.iters)
