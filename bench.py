@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--sims", type=int, default=200, help="MCTS simulations per move")
     ap.add_argument("--sets", type=int, default=4, help="independent game sets per GPU, one HIP stream each (engine.MultiSetSelfPlay)")
     ap.add_argument("--gnn-batch", type=int, default=4096)
+    ap.add_argument("--trunk-variant", type=int, default=3, help="developer knob: aqg_set_option trunk_variant (3 = per-launch choice)")
     ap.add_argument("--trunk-grid", type=int, default=0, help="developer knob: cap the trunk's persistent grid (0 = default 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--large-games", type=int, default=16384,
@@ -99,6 +100,8 @@ def main():
 
     if args.trunk_grid:
         _lib.set_option("trunk_grid", args.trunk_grid)
+    if args.trunk_variant != 3:
+        _lib.set_option("trunk_variant", args.trunk_variant)
     torch.manual_seed(0)                 # random-init weights of the reference architecture (synthetic; no checkpoints)
     model = GNNNetwork().to(dev).eval()
     eng = MultiSetSelfPlay(model, num_games=args.games, sims=args.sims, num_sets=args.sets, seed=1000 + rank)
