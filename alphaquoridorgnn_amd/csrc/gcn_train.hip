@@ -158,13 +158,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
     }
 }
 
-// out[i] = sum_z part[z * n + i], slices added in index order (deterministic)
-__global__ void reduce_partials_kernel(const float* __restrict__ part, size_t n, int slices, float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int z = 0; z < slices; ++z) s += part[(size_t)z * n + i];
-    out[i] = s;
+// All sliced reductions of a step are finished by ONE launch: job j sums `slices` partial arrays of n floats starting
+// at part + off into out, slices added in index order (deterministic).  blockIdx.y = job.
+struct ReduceJobs {
+    int count;
+    unsigned long long off[14];
+    unsigned int n[14];
+    int slices[14];
+    float* out[14];
+};
+__global__ void reduce_jobs_kernel(const float* __restrict__ part, ReduceJobs jobs) {
+    const int j = blockIdx.y;
+    const unsigned int n = jobs.n[j];
+    const float* src = part + jobs.off[j];
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < jobs.slices[j]; ++z) s += src[(size_t)z * n + i];
+        jobs.out[j][i] = s;
+    }
 }
 
 // ELL aggregation, one wavefront per node (2 columns per lane): out[n] = sum_s w[n][s] * Z[idx[n][s]] (+ bias) (relu)
@@ -246,17 +257,27 @@ __global__ __launch_bounds__(256) void loss_kernel(float* __restrict__ lg, float
     }
 }
 
-// torch.optim.Adam.step() (single tensor, no weight decay, no amsgrad), bias corrections computed on the host in f64
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
-                            float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float gi = g[i];
-    const float mi = beta1 * m[i] + (1.f - beta1) * gi;          // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-    m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] -= (lr / bc1) * (mi / denom);
+// torch.optim.Adam.step() for all 14 tensors in one launch (no weight decay, no amsgrad); bias corrections computed on
+// the host in f64.  blockIdx.y = tensor.
+struct AdamJobs {
+    float* p[14]; const float* g[14]; float* m[14]; float* v[14];
+    unsigned int n[14];
+};
+__global__ void adam_kernel(AdamJobs jobs, float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+    const int j = blockIdx.y;
+    const unsigned int n = jobs.n[j];
+    float* __restrict__ p = jobs.p[j];
+    const float* __restrict__ g = jobs.g[j];
+    float* __restrict__ m = jobs.m[j];
+    float* __restrict__ v = jobs.v[j];
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;          // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -269,33 +290,38 @@ static void gemm(hipStream_t st, bool relu, bool acc, const float* X, int R, int
     else if (!relu && acc) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, st, X, R, S, W, sc, ss, bias, C, Y);
     else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, X, R, S, W, sc, ss, bias, C, Y);
 }
-constexpr int TRAIN_SLICE_ROWS = 256;     // rows per partial sum
-constexpr int TRAIN_MAX_SLICES = 64;      // aqg_train.part holds TRAIN_MAX_SLICES * 128 * 128 floats
+constexpr int TRAIN_SLICE_ROWS = 256;           // rows per partial sum
+constexpr int TRAIN_MAX_SLICES = 64;
+constexpr size_t TRAIN_PART_FLOATS = 64 * (2 * 128 * 128 + 128 * 8 + 3 * 128);   // aqg_train.part: every partial array of one step at 64 slices
 
-static void wgrad(hipStream_t st, float* part, const float* A, int Ja, const float* Bm, int Kb, int R, float* G) {
+struct PartialSums {                            // bump allocator over aqg_train.part + the list of pending reductions
+    float* part;
+    size_t used = 0;
+    ReduceJobs jobs{};
+    float* take(size_t n, int slices, float* out) {
+        float* dst = part + used;
+        jobs.off[jobs.count] = used; jobs.n[jobs.count] = (unsigned int)n; jobs.slices[jobs.count] = slices; jobs.out[jobs.count] = out;
+        ++jobs.count;
+        used += n * slices;
+        return dst;
+    }
+};
+
+static void wgrad(hipStream_t st, PartialSums& ps, const float* A, int Ja, const float* Bm, int Kb, int R, float* G) {
     int slices = (R + TRAIN_SLICE_ROWS - 1) / TRAIN_SLICE_ROWS;
     if (slices > TRAIN_MAX_SLICES) slices = TRAIN_MAX_SLICES;
     const int rows = ((R + slices - 1) / slices + 31) / 32 * 32;
     const dim3 grid((Ja + 31) / 32, (Kb + 31) / 32, slices);
-    if (slices == 1) {
-        hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, A, Ja, Bm, Kb, R, rows, G);
-        return;
-    }
-    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, A, Ja, Bm, Kb, R, rows, part);
-    const size_t n = (size_t)Ja * Kb;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)part, n, slices, G);
+    float* dst = slices == 1 ? G : ps.take((size_t)Ja * Kb, slices, G);
+    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, A, Ja, Bm, Kb, R, rows, dst);
 }
-static void colsum(hipStream_t st, float* part, const float* A, int R, int C, float* out) {
+static void colsum(hipStream_t st, PartialSums& ps, const float* A, int R, int C, float* out) {
     int slices = (R + TRAIN_SLICE_ROWS - 1) / TRAIN_SLICE_ROWS;
     if (slices > TRAIN_MAX_SLICES) slices = TRAIN_MAX_SLICES;
     const int rows = ((R + slices - 1) / slices + 7) / 8 * 8;
     const dim3 grid((C + 31) / 32, slices);
-    if (slices == 1) {
-        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, A, R, C, rows, out);
-        return;
-    }
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, A, R, C, rows, part);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, (const float*)part, (size_t)C, slices, out);
+    float* dst = slices == 1 ? out : ps.take((size_t)C, slices, out);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, A, R, C, rows, dst);
 }
 
 // parameter order = state_dict order (KEYS in INTEGRATION.md):
@@ -329,20 +355,22 @@ int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, con
     // ---- loss and its gradient wrt logits (t.lg) / pre-tanh value (t.vp), in place
     hipLaunchKernelGGL(loss_kernel, dim3(B), dim3(256), 0, st, t.lg, t.pol, t.vp, t.val, pi, z, A, B, t.loss);
     if (int r = check_launch("training forward kernels")) return r;
-    // ---- backward: heads
-    wgrad(st, t.part, t.lg, A, t.hp, H2, B, G[8]);
-    colsum(st, t.part, t.lg, B, A, G[9]);
+    // ---- backward: heads (every sliced reduction parks its partial sums in t.part; one launch finishes them all)
+    PartialSums ps;
+    ps.part = t.part;
+    wgrad(st, ps, t.lg, A, t.hp, H2, B, G[8]);
+    colsum(st, ps, t.lg, B, A, G[9]);
     gemm(st, false, false, t.lg, B, A, P[8], 1, H2, nullptr, H2, t.dhp);           // dhp = dlogits W_p2
     hipLaunchKernelGGL(relu_mask_kernel, dim3((B * H2 + 255) / 256), dim3(256), 0, st, t.dhp, (const float*)t.hp, (size_t)B * H2);
-    wgrad(st, t.part, t.dhp, H2, t.g, TH, B, G[6]);
-    colsum(st, t.part, t.dhp, B, H2, G[7]);
+    wgrad(st, ps, t.dhp, H2, t.g, TH, B, G[6]);
+    colsum(st, ps, t.dhp, B, H2, G[7]);
     gemm(st, false, false, t.dhp, B, H2, P[6], 1, TH, nullptr, TH, t.dg);           // dg = dhp W_p1
-    wgrad(st, t.part, t.vp, 1, t.hv, H2, B, G[12]);
-    colsum(st, t.part, t.vp, B, 1, G[13]);
+    wgrad(st, ps, t.vp, 1, t.hv, H2, B, G[12]);
+    colsum(st, ps, t.vp, B, 1, G[13]);
     gemm(st, false, false, t.vp, B, 1, P[12], 1, H2, nullptr, H2, t.dhv);
     hipLaunchKernelGGL(relu_mask_kernel, dim3((B * H2 + 255) / 256), dim3(256), 0, st, t.dhv, (const float*)t.hv, (size_t)B * H2);
-    wgrad(st, t.part, t.dhv, H2, t.g, TH, B, G[10]);
-    colsum(st, t.part, t.dhv, B, H2, G[11]);
+    wgrad(st, ps, t.dhv, H2, t.g, TH, B, G[10]);
+    colsum(st, ps, t.dhv, B, H2, G[11]);
     gemm(st, false, true, t.dhv, B, H2, P[10], 1, TH, nullptr, TH, t.dg);           // dg += dhv W_v1
     // ---- backward: trunk
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(B), dim3(128), 0, st, (const float*)t.dg, V, t.dh);
@@ -352,13 +380,15 @@ int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, con
     float* hout[3] = {t.h1, t.h2, t.h3};
     for (int L = 2; L >= 0; --L) {
         hipLaunchKernelGGL(relu_mask_kernel, mg, mb, 0, st, t.dh, (const float*)hout[L], nel);      // dP
-        colsum(st, t.part, t.dh, R, TH, G[2 * L + 1]);
+        colsum(st, ps, t.dh, R, TH, G[2 * L + 1]);
         hipLaunchKernelGGL(agg_kernel<false>, ag, ab, 0, st, (const float*)t.dh, R, (const int32_t*)t.ell_idx, (const float*)t.ell_w,
                            (const float*)nullptr, t.zbuf);                                          // dZ = A_hat dP
         const int K = L == 0 ? TF : TH;
-        wgrad(st, t.part, t.zbuf, TH, hin[L], K, R, G[2 * L]);
+        wgrad(st, ps, t.zbuf, TH, hin[L], K, R, G[2 * L]);
         if (L > 0) gemm(st, false, false, t.zbuf, R, TH, P[2 * L], 1, TH, nullptr, TH, t.dh);       // dH_{L-1} = dZ W_L
     }
+    if (ps.used > TRAIN_PART_FLOATS) return fail("training: partial-sum workspace too small for this batch");
+    if (ps.jobs.count) hipLaunchKernelGGL(reduce_jobs_kernel, dim3(16, ps.jobs.count), dim3(256), 0, st, (const float*)t.part, ps.jobs);
     if (int r = check_launch("training backward kernels")) return r;
     }
     // ---- Adam
@@ -366,9 +396,9 @@ int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, con
         const double bc1 = 1.0 - pow((double)t.beta1, (double)t.step), bc2 = 1.0 - pow((double)t.beta2, (double)t.step);
         const size_t sizes[14] = {(size_t)TH * TF, TH, (size_t)TH * TH, TH, (size_t)TH * TH, TH, (size_t)H2 * TH, (size_t)H2, (size_t)A * H2, (size_t)A,
                                   (size_t)H2 * TH, (size_t)H2, (size_t)H2, 1};
-        for (int i = 0; i < 14; ++i)
-            hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((sizes[i] + 255) / 256)), dim3(256), 0, st, P[i], (const float*)G[i], t.adam_m[i],
-                               t.adam_v[i], sizes[i], t.lr, t.beta1, t.beta2, t.eps, (float)bc1, (float)sqrt(bc2));
+        AdamJobs aj;
+        for (int i = 0; i < 14; ++i) { aj.p[i] = P[i]; aj.g[i] = G[i]; aj.m[i] = t.adam_m[i]; aj.v[i] = t.adam_v[i]; aj.n[i] = (unsigned int)sizes[i]; }
+        hipLaunchKernelGGL(adam_kernel, dim3(16, 14), dim3(256), 0, st, aj, t.lr, t.beta1, t.beta2, t.eps, (float)bc1, (float)sqrt(bc2));
         if (int r = check_launch("adam_kernel")) return r;
     }
     return 0;

@@ -73,7 +73,7 @@ class GNNTrainer:
             g=torch.empty((B, H), **f), dg=torch.empty((B, H), **f), hp=torch.empty((B, H // 2), **f),
             hv=torch.empty((B, H // 2), **f), dhp=torch.empty((B, H // 2), **f), dhv=torch.empty((B, H // 2), **f),
             lg=torch.empty((B, A), **f), pol=torch.empty((B, A), **f), vp=torch.empty((B,), **f), val=torch.empty((B,), **f),
-            loss=torch.empty((B, 2), **f), part=torch.empty((64 * 128 * 128,), **f))
+            loss=torch.empty((B, 2), **f), part=torch.empty((64 * (2 * 128 * 128 + 128 * 8 + 3 * 128),), **f))
         t = self.t = _lib.TrainStruct()
         t.board_size, t.policy_size = self.N, self.A
         t.beta1, t.beta2, t.eps = float(betas[0]), float(betas[1]), float(eps)

@@ -186,7 +186,7 @@ typedef struct aqg_train {
     float* pol;                   /* [B, A]     softmax policy (the network output) */
     float* vp; float* val;        /* [B]        pre-tanh value (overwritten by its gradient), tanh value */
     float* loss;                  /* [B, 2]     per-position policy / value loss terms (their means are the two losses) */
-    float* part;                  /* [64 * 128 * 128] partial sums of the row-sliced gradient reductions */
+    float* part;                  /* [64 * (2*128*128 + 128*8 + 3*128) = 2,187,264 floats] partial sums of the row-sliced gradient reductions */
 } aqg_train;
 int aqg_gcn_train_step(const aqg_train* t_host, const uint8_t* states72, const float* pi_target, const float* z_target,
                        int mode, void* stream);
