@@ -12,5 +12,5 @@ for f in legal_mask gcn_forward gcn_train mcts capi; do
   objs+=(${OBJDIR}/aqg_$f.o)
 done
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT "${objs[@]}"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT "${objs[@]}" -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib
 echo "built $(realpath $OUT)"

@@ -14,6 +14,7 @@
 //   update    torch.optim.Adam (lr, betas, eps; bias-corrected; no weight decay, no amsgrad)
 #include "aqg_common.hpp"
 #include "../../include/aqgnn.h"
+#include <rocblas/rocblas.h>
 
 namespace aqg {
 
@@ -324,6 +325,44 @@ static void colsum(hipStream_t st, PartialSums& ps, const float* A, int R, int C
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, A, R, C, rows, dst);
 }
 
+// The three GEMM shapes over all B*V node rows -- Z = H W^T, dH = dZ W, dW = dZ^T H -- are plain dense f32 GEMMs with
+// nothing to fuse: they go to rocBLAS (f32 MFMA kernels; atomics off, so results stay run-to-run identical).  Row-major
+// operands are handed over as their column-major transposes.
+static rocblas_handle blas_handle(hipStream_t st) {
+    static rocblas_handle h = nullptr;
+    if (!h) {
+        if (rocblas_create_handle(&h) != rocblas_status_success) { h = nullptr; return nullptr; }
+        rocblas_set_atomics_mode(h, rocblas_atomics_not_allowed);
+        rocblas_set_pointer_mode(h, rocblas_pointer_mode_host);
+    }
+    rocblas_set_stream(h, st);
+    return h;
+}
+// Z[R][C] = X[R][S] * W[C][S]^T
+static int blas_forward(hipStream_t st, const float* X, int R, int S, const float* W, int C, float* Z) {
+    rocblas_handle h = blas_handle(st);
+    const float one = 1.f, zero = 0.f;
+    if (!h || rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, C, R, S, &one, W, S, X, S, &zero, Z, C) != rocblas_status_success)
+        return fail("rocblas_sgemm (forward)");
+    return 0;
+}
+// dX[R][K] = dY[R][J] * W[J][K]
+static int blas_dgrad(hipStream_t st, const float* dY, int R, int J, const float* W, int K, float* dX) {
+    rocblas_handle h = blas_handle(st);
+    const float one = 1.f, zero = 0.f;
+    if (!h || rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, K, R, J, &one, W, K, dY, J, &zero, dX, K) != rocblas_status_success)
+        return fail("rocblas_sgemm (data gradient)");
+    return 0;
+}
+// dW[J][K] = dY[R][J]^T * X[R][K]
+static int blas_wgrad(hipStream_t st, const float* dY, int J, const float* X, int K, int R, float* dW) {
+    rocblas_handle h = blas_handle(st);
+    const float one = 1.f, zero = 0.f;
+    if (!h || rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, K, J, R, &one, X, K, dY, J, &zero, dW, K) != rocblas_status_success)
+        return fail("rocblas_sgemm (weight gradient)");
+    return 0;
+}
+
 // parameter order = state_dict order (KEYS in INTEGRATION.md):
 //  0 gcn0.w [H,F]  1 gcn0.b  2 gcn1.w [H,H]  3 gcn1.b  4 gcn2.w  5 gcn2.b
 //  6 pol0.w [H/2,H]  7 pol0.b  8 pol2.w [A,H/2]  9 pol2.b  10 val0.w [H/2,H]  11 val0.b  12 val2.w [1,H/2]  13 val2.b
@@ -341,11 +380,11 @@ int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, con
 #define CALL_PREP(n) hipLaunchKernelGGL(train_prep_kernel<n>, dim3((R + 255) / 256), dim3(256), 0, st, states72, B, t.x0, t.ell_idx, t.ell_w)
     switch (N) { case 3: CALL_PREP(3); break; case 5: CALL_PREP(5); break; case 7: CALL_PREP(7); break; default: CALL_PREP(9); break; }
     const dim3 ag((R + 3) / 4), ab(256);
-    gemm(st, false, false, t.x0, R, TF, P[0], TF, 1, nullptr, TH, t.zbuf);
+    if (int r = blas_forward(st, t.x0, R, TF, P[0], TH, t.zbuf)) return r;
     hipLaunchKernelGGL(agg_kernel<true>, ag, ab, 0, st, (const float*)t.zbuf, R, (const int32_t*)t.ell_idx, (const float*)t.ell_w, (const float*)P[1], t.h1);
-    gemm(st, false, false, t.h1, R, TH, P[2], TH, 1, nullptr, TH, t.zbuf);
+    if (int r = blas_forward(st, t.h1, R, TH, P[2], TH, t.zbuf)) return r;
     hipLaunchKernelGGL(agg_kernel<true>, ag, ab, 0, st, (const float*)t.zbuf, R, (const int32_t*)t.ell_idx, (const float*)t.ell_w, (const float*)P[3], t.h2);
-    gemm(st, false, false, t.h2, R, TH, P[4], TH, 1, nullptr, TH, t.zbuf);
+    if (int r = blas_forward(st, t.h2, R, TH, P[4], TH, t.zbuf)) return r;
     hipLaunchKernelGGL(agg_kernel<true>, ag, ab, 0, st, (const float*)t.zbuf, R, (const int32_t*)t.ell_idx, (const float*)t.ell_w, (const float*)P[5], t.h3);
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(B), dim3(128), 0, st, (const float*)t.h3, V, t.g);
     gemm(st, true, false, t.g, B, TH, P[6], TH, 1, P[7], H2, t.hp);
@@ -384,8 +423,8 @@ int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, con
         hipLaunchKernelGGL(agg_kernel<false>, ag, ab, 0, st, (const float*)t.dh, R, (const int32_t*)t.ell_idx, (const float*)t.ell_w,
                            (const float*)nullptr, t.zbuf);                                          // dZ = A_hat dP
         const int K = L == 0 ? TF : TH;
-        wgrad(st, ps, t.zbuf, TH, hin[L], K, R, G[2 * L]);
-        if (L > 0) gemm(st, false, false, t.zbuf, R, TH, P[2 * L], 1, TH, nullptr, TH, t.dh);       // dH_{L-1} = dZ W_L
+        if (int r = blas_wgrad(st, t.zbuf, TH, hin[L], K, R, G[2 * L])) return r;
+        if (L > 0) { if (int r = blas_dgrad(st, t.zbuf, R, TH, P[2 * L], TH, t.dh)) return r; }   // dH_{L-1} = dZ W_L
     }
     if (ps.used > TRAIN_PART_FLOATS) return fail("training: partial-sum workspace too small for this batch");
     if (ps.jobs.count) hipLaunchKernelGGL(reduce_jobs_kernel, dim3(16, ps.jobs.count), dim3(256), 0, st, (const float*)t.part, ps.jobs);
