@@ -790,7 +790,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
                                                                                         float* __restrict__ pooled,
                                                                                         const uint8_t* __restrict__ active, int phase_delay) {
     constexpr int N = 9, V = 81, S = 8;
-    constexpr int NWV = 8 / JT, NTHR = 64 * NWV;
+    constexpr int NWV = 8 / JT;
     __shared__ TrunkSmemM sm;
     // The two workgroups resident on a CU run identical phase sequences; a start offset for the second-resident ones
     // (phase_delay x 64 cycles) keeps one on the matrix pipe while the other does vector work.

@@ -366,16 +366,11 @@ static int blas_wgrad(hipStream_t st, const float* dY, int J, const float* X, in
 // parameter order = state_dict order (KEYS in INTEGRATION.md):
 //  0 gcn0.w [H,F]  1 gcn0.b  2 gcn1.w [H,H]  3 gcn1.b  4 gcn2.w  5 gcn2.b
 //  6 pol0.w [H/2,H]  7 pol0.b  8 pol2.w [A,H/2]  9 pol2.b  10 val0.w [H/2,H]  11 val0.b  12 val2.w [1,H/2]  13 val2.b
-int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, const float* z, int mode, hipStream_t st) {
+static int train_gradients(const aqg_train& t, const uint8_t* states72, const float* pi, const float* z, hipStream_t st) {
     const int N = t.board_size, B = t.batch, A = t.policy_size;
-    const int do_update = mode >= 1, do_grads = mode != 2;     // 0 gradients only, 1 gradients + Adam, 2 Adam only
-    if (!(N == 3 || N == 5 || N == 7 || N == 9)) return fail("board_size must be 3, 5, 7 or 9");
-    if (A != N * N + 2 * (N - 1) * (N - 1) || A > 256) return fail("policy_size does not match the board");
-    if (B <= 0 && mode != 2) return 0;
     const int V = N * N, R = B * V, H2 = TH / 2;
     float* const* P = t.params;
     float* const* G = t.grads;
-    if (do_grads) {
     // ---- forward
 #define CALL_PREP(n) hipLaunchKernelGGL(train_prep_kernel<n>, dim3((R + 255) / 256), dim3(256), 0, st, states72, B, t.x0, t.ell_idx, t.ell_w)
     switch (N) { case 3: CALL_PREP(3); break; case 5: CALL_PREP(5); break; case 7: CALL_PREP(7); break; default: CALL_PREP(9); break; }
@@ -429,16 +424,30 @@ int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, con
     if (ps.used > TRAIN_PART_FLOATS) return fail("training: partial-sum workspace too small for this batch");
     if (ps.jobs.count) hipLaunchKernelGGL(reduce_jobs_kernel, dim3(16, ps.jobs.count), dim3(256), 0, st, (const float*)t.part, ps.jobs);
     if (int r = check_launch("training backward kernels")) return r;
+    return 0;
+}
+
+static int train_update(const aqg_train& t, hipStream_t st) {
+    const int A = t.policy_size, H2 = TH / 2;
+    const double bc1 = 1.0 - pow((double)t.beta1, (double)t.step), bc2 = 1.0 - pow((double)t.beta2, (double)t.step);
+    const size_t sizes[14] = {(size_t)TH * TF, TH, (size_t)TH * TH, TH, (size_t)TH * TH, TH, (size_t)H2 * TH, (size_t)H2, (size_t)A * H2, (size_t)A,
+                              (size_t)H2 * TH, (size_t)H2, (size_t)H2, 1};
+    AdamJobs aj;
+    for (int i = 0; i < 14; ++i) { aj.p[i] = t.params[i]; aj.g[i] = t.grads[i]; aj.m[i] = t.adam_m[i]; aj.v[i] = t.adam_v[i]; aj.n[i] = (unsigned int)sizes[i]; }
+    hipLaunchKernelGGL(adam_kernel, dim3(16, 14), dim3(256), 0, st, aj, t.lr, t.beta1, t.beta2, t.eps, (float)bc1, (float)sqrt(bc2));
+    return check_launch("adam_kernel");
+}
+
+// mode 0 = gradients only, 1 = gradients + Adam, 2 = Adam only (data-parallel: local gradients, all-reduce, update)
+int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, const float* z, int mode, hipStream_t st) {
+    const int N = t.board_size, A = t.policy_size;
+    if (!(N == 3 || N == 5 || N == 7 || N == 9)) return fail("board_size must be 3, 5, 7 or 9");
+    if (A != N * N + 2 * (N - 1) * (N - 1) || A > 256) return fail("policy_size does not match the board");
+    if (mode != 2 && t.batch > 0) {
+        if (int r = train_gradients(t, states72, pi, z, st)) return r;
     }
-    // ---- Adam
-    if (do_update) {
-        const double bc1 = 1.0 - pow((double)t.beta1, (double)t.step), bc2 = 1.0 - pow((double)t.beta2, (double)t.step);
-        const size_t sizes[14] = {(size_t)TH * TF, TH, (size_t)TH * TH, TH, (size_t)TH * TH, TH, (size_t)H2 * TH, (size_t)H2, (size_t)A * H2, (size_t)A,
-                                  (size_t)H2 * TH, (size_t)H2, (size_t)H2, 1};
-        AdamJobs aj;
-        for (int i = 0; i < 14; ++i) { aj.p[i] = P[i]; aj.g[i] = G[i]; aj.m[i] = t.adam_m[i]; aj.v[i] = t.adam_v[i]; aj.n[i] = (unsigned int)sizes[i]; }
-        hipLaunchKernelGGL(adam_kernel, dim3(16, 14), dim3(256), 0, st, aj, t.lr, t.beta1, t.beta2, t.eps, (float)bc1, (float)sqrt(bc2));
-        if (int r = check_launch("adam_kernel")) return r;
+    if (mode >= 1 && (t.batch > 0 || mode == 2)) {
+        if (int r = train_update(t, st)) return r;
     }
     return 0;
 }

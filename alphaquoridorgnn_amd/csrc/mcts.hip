@@ -475,6 +475,8 @@ static int enqueue_sims(const aqg_engine& e, hipStream_t st) {
 // captured once into a hipGraph and replayed per move, so the host cost per move is one graph launch instead of ~600
 // kernel launches (with several game sets on several streams the host is otherwise the bottleneck).  The cache key is
 // the engine struct itself plus the trunk options the launches read.
+// (Host entry points are called from one host thread per process, like the reference's single-threaded loop; the cache
+// below and the library's other host-side globals are not synchronised.)
 struct SimGraph {
     aqg_engine e;
     int opts[4];
