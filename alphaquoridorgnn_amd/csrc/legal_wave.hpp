@@ -16,32 +16,31 @@ template <int N>
 __device__ __forceinline__ int wave_legal_actions(const QState& s, int lane, uint8_t* __restrict__ mask,
                                                   uint8_t* __restrict__ order) {
     constexpr int V = Geo<N>::V, NW = Geo<N>::NW, A = Geo<N>::A;
-    const Open base = make_open<N>(s.hw, s.vw);
+    // The wall masks are the same in every lane: as wave-uniform scalars, the open-edge bitboards, the placement masks
+    // and the touch-count prefilter of ALL slots are computed once per wave on the scalar unit; lanes only test bits.
+    const uint64_t hw = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(s.hw >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s.hw);
+    const uint64_t vw = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(s.vw >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s.vw);
+    const Open base = make_open<N>(hw, vw);
     // Step 1 (lane = wall slot): geometric placement and the touch-count prefilter.  A placeable candidate that
     // the prefilter clears is legal outright (game_logic.py:327-328); the others need the two path searches.
     bool placeH = false, placeV = false, needH = false, needV = false;
-#if defined(AQG_LEGAL_DIAG) && AQG_LEGAL_DIAG >= 2   // ... and no placement / prefilter step either
-    if (false) {
-#else
     if (s.pwl > 0 && lane < NW) {
-#endif
-        uint64_t hp, vp;
-        placeable_masks<N>(s.hw, s.vw, hp, vp);
+        uint64_t hp, vp, hb, vb;
+        placeable_masks<N>(hw, vw, hp, vp);
+        possibly_blocking_masks<N>(hw, vw, hb, vb);
         placeH = (hp >> lane) & 1;
         placeV = (vp >> lane) & 1;
-        needH = placeH && possibly_blocking<N>(s.hw, s.vw, 1, lane);
-        needV = placeV && possibly_blocking<N>(s.hw, s.vw, 2, lane);
+        needH = placeH && ((hb >> lane) & 1);
+        needV = placeV && ((vb >> lane) & 1);
     }
     const uint64_t pH = __ballot(placeH), pV = __ballot(placeV), nH = __ballot(needH), nV = __ballot(needV);
     // Step 2 (lane = task): the k-th candidate that needs the searches (H candidates in slot order, then V) goes to
     // lane k, which runs the mover's and the enemy's flood fill interleaved (can_reach2: two independent dependency
     // chains keep a lone wavefront's VALU busy; one fill per lane and twice the rounds measured slower).
     const int cH = __popcll(nH), cV = __popcll(nV);
-#if defined(AQG_LEGAL_DIAG) && AQG_LEGAL_DIAG >= 1   // timing experiments only (wrong results): no flood fills
-    const int ntask = 0;
-#else
     const int ntask = cH + cV;
-#endif
     uint64_t failH = 0, failV = 0;
     for (int tbase = 0; tbase < ntask; tbase += 64) {
         const int task = tbase + lane;
