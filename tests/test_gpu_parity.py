@@ -17,7 +17,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
-DRAW = {9: 116, 5: 28}
+DRAW = {9: 116, 5: 28, 3: 14}
 
 
 @pytest.fixture(scope="module")
@@ -37,7 +37,7 @@ def _model(seed=0):
 
 
 # ------------------------------------------------------------------ K3 legal actions / S7 next / S1 status
-@pytest.mark.parametrize("N", [9, 5])
+@pytest.mark.parametrize("N", [9, 5, 3])
 def test_legal_actions_golden(dev, N):
     from alphaquoridorgnn_amd import game_logic as gl
     g = U.golden(f"walk_{N}x{N}.npz")
@@ -222,7 +222,7 @@ def test_predict_contract(dev):
 
 
 # ------------------------------------------------------------------ K4 MCTS / self-play against reference traces
-@pytest.mark.parametrize("N", [9, 5])
+@pytest.mark.parametrize("N", [9, 5, 3])
 def test_mcts_visit_counts_match_reference_traces(dev, N):
     """Golden traces were produced by the REAL reference pv_mcts.py with the integer-hash fake model; the engine's
     `fake` evaluator reproduces that model exactly, so visit distributions must be bit-identical."""
@@ -240,7 +240,7 @@ def test_mcts_visit_counts_match_reference_traces(dev, N):
             assert np.array_equal(np.asarray(pol, dtype=np.float64), g[f"t{k}_policy"]), (k, sims, bias, T)
 
 
-@pytest.mark.parametrize("N", [9, 5])
+@pytest.mark.parametrize("N", [9, 5, 3])
 def test_selfplay_games_match_reference(dev, N):
     """Whole games through the engine == the reference's self_play.play() (seeded np.random, fake model):
     same states, same visit distributions (float64-exact), same z."""

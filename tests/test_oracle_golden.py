@@ -7,7 +7,7 @@ from oracle import quoridor as oq
 from oracle import mcts as om
 from tests import _util as U
 
-DRAW = {9: 116, 5: 28}
+DRAW = {9: 116, 5: 28, 3: 14}
 
 
 def test_reference_known_answers_9x9():
@@ -48,7 +48,7 @@ def test_survey_documented_jumps():
         assert oq.legal_actions_pos(rec, pp) == exp
 
 
-@pytest.mark.parametrize("N", [9, 5])
+@pytest.mark.parametrize("N", [9, 5, 3])
 def test_walk_states_bit_exact(N):
     g = U.golden(f"walk_{N}x{N}.npz")
     recs, legal, counts = g["states"], g["legal"], g["counts"]
@@ -80,7 +80,7 @@ def test_pawn_obstacle_counter_examples():
         assert [int(x) for x in a[0, :c[0]]] == exp
 
 
-@pytest.mark.parametrize("N", [9, 5])
+@pytest.mark.parametrize("N", [9, 5, 3])
 def test_mcts_traces_match_reference(N):
     g = U.golden(f"mcts_{N}x{N}.npz")
     n = int(g["count"][0])
@@ -96,7 +96,7 @@ def test_mcts_traces_match_reference(N):
     assert checked >= 10
 
 
-@pytest.mark.parametrize("N", [9, 5])
+@pytest.mark.parametrize("N", [9, 5, 3])
 def test_full_games_match_reference(N):
     g = U.golden(f"games_{N}x{N}.npz")
     for i in range(int(g["count"][0])):
