@@ -129,12 +129,11 @@ __global__ void engine_begin_move_kernel(aqg_engine e) {
 // select: descend by PUCT to a terminal node (back up at once) or to an unexpanded leaf (emit its state)
 // ------------------------------------------------------------------------------------------------
 template <int N>
-__device__ __forceinline__ void game_select(const aqg_engine& e, int g, int lane) {
-    if (!e.game_active[g]) { if (lane == 0) e.leaf_flag[g] = 0; return; }
+__device__ __forceinline__ void game_select(const aqg_engine& e, int g, int lane, int active, QState s) {
+    if (!active) { if (lane == 0) e.leaf_flag[g] = 0; return; }
     if (lane == 0) e.leaf_flag[g] = 0;
     NodeRec* __restrict__ nodes = game_nodes(e, g);
     int* path = e.path + (size_t)g * (e.sims + 2);
-    QState s = load_state(e.root_state, 1, g);
     int node = 0, depth = 0;
     int mynode = 0;                      // lane d keeps the path node at depth d (d < 64) in a register
     if (lane == 0) path[0] = 0;
@@ -273,23 +272,29 @@ __global__ __launch_bounds__(256) void engine_fake_eval_kernel(aqg_engine e) {
 // expand + backup (pv_mcts.py:47-57, :60-66)
 // ------------------------------------------------------------------------------------------------
 template <int N>
-__device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, int lane) {
+__device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, int lane, int flag, int depth, int cnt, int first,
+                                                   float leaf_value) {
     constexpr int A = Geo<N>::A;
-    if (e.leaf_flag[g] != 1) return;
+    // Round 1 of loads: everything whose address depends on nothing but g and the lane -- the caller's five scalars, this
+    // lane's legal-action bytes and its path entry -- is requested before the first branch, so the wave pays ONE memory
+    // round trip here instead of one per dependent step (the whole kernel is a latency chain).
     NodeRec* __restrict__ nodes = game_nodes(e, g);
     const int* path = e.path + (size_t)g * (e.sims + 2);
-    const int depth = e.path_len[g];
-    const int leaf = path[depth];
-    const int cnt = e.legal_count[g];
     const uint8_t* ord = e.legal_order + (size_t)g * MAX_LEGAL;
     const float* pol = e.policy + (size_t)g * A;
+    uint8_t oa[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { const int i = lane + 64 * r; oa[r] = (i < MAX_LEGAL) ? ord[i] : (uint8_t)0; }
+    const int pnode = (lane < e.sims + 2) ? path[lane] : 0;           // path node at depth `lane`
+    if (flag != 1) return;
+    const int leaf = depth < 64 ? __shfl(pnode, depth) : path[depth];
     float pl[3];
     if (e.prior_mode == 0) {       // P0: gather at legal actions, divide by the sum unless 0 (pv_network_cnn.py:129-132)
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int i = lane + 64 * r;
-            pl[r] = (i < cnt) ? pol[ord[i]] : 0.f;
+            pl[r] = (i < cnt) ? pol[oa[r]] : 0.f;
             sum += pl[r];
         }
         sum = wave_sum_f(sum);
@@ -303,14 +308,13 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
             pl[r] = (i < cnt) ? pol[i] : 0.f;
         }
     }
-    const int first = e.node_count[g];
     if (first + cnt <= e.node_cap && cnt > 0) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int i = lane + 64 * r;
             if (i < cnt) {
                 NodeRec c;
-                c.w = 0.0; c.p = pl[r]; c.n = 0; c.kids = 0; c.action = ord[i]; c.pad[0] = 0; c.pad[1] = 0;
+                c.w = 0.0; c.p = pl[r]; c.n = 0; c.kids = 0; c.action = oa[r]; c.pad[0] = 0; c.pad[1] = 0;
                 nodes[first + i] = c;
             }
         }
@@ -319,7 +323,21 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
         nodes[leaf].kids = (uint32_t)first | ((uint32_t)cnt << 24);
         e.node_count[g] = first + cnt;
     }
-    backup_path(nodes, path, depth, (double)e.value[g], lane);   // value.item() -> python float
+    // backup (pv_mcts.py:60-66): lane d updates the path node at depth d from its register copy; deeper parts of a path
+    // (practically unreachable) go through memory
+    {
+        const double v = (double)leaf_value;                       // value.item() -> python float
+        if (lane <= depth) {
+            NodeRec& r = nodes[pnode];
+            r.w += ((depth - lane) & 1) ? -v : v;
+            r.n += 1;
+        }
+        for (int d = lane + 64; d <= depth; d += 64) {
+            NodeRec& r = nodes[path[d]];
+            r.w += ((depth - d) & 1) ? -v : v;
+            r.n += 1;
+        }
+    }
     if (lane == 0) e.stat_leaf_evals[g] += 1;   // per-game slot: a shared counter would serialise 2048 atomics per step
 }
 
@@ -335,14 +353,20 @@ __global__ __launch_bounds__(256) void engine_step_kernel(aqg_engine e, int do_e
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= e.num_games) return;
-    if (do_expand) game_expand_backup<N>(e, g, lane);
+    // loads that depend on nothing but g: one round for both halves of the step
+    const int active = e.game_active[g];
+    const QState root = load_state(e.root_state, 1, g);
+    int flag = 0, depth = 0, cnt = 0, first = 0;
+    float value = 0.f;
+    if (do_expand) { flag = e.leaf_flag[g]; depth = e.path_len[g]; cnt = e.legal_count[g]; first = e.node_count[g]; value = e.value[g]; }
+    if (do_expand) game_expand_backup<N>(e, g, lane, flag, depth, cnt, first, value);
     if (do_select) {
         if (do_expand) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        game_select<N>(e, g, lane);
+        game_select<N>(e, g, lane, active, root);
     }
 }
 
