@@ -8,6 +8,7 @@ extern int g_trunk_variant;
 extern int g_profile_trunk;
 extern int g_trunk_grid;
 extern int g_trunk_phase_delay;
+extern int g_trunk_delay_min_boards;
 extern int g_use_graph;
 int profile_collect(double* total_ms, long long* launches, long long* boards, int reset);
 int launch_poison_lds(hipStream_t st);
@@ -43,6 +44,7 @@ int aqg_set_option(const char* name, int value) {
     if (name && !strcmp(name, "trunk_variant")) { if (!(value == 0 || value == 1 || value == 3 || value == 4 || value == 5 || value == 6)) return fail("trunk_variant must be 0, 1, 3, 4, 5 or 6"); g_trunk_variant = value; return 0; }
     if (name && !strcmp(name, "trunk_grid")) { g_trunk_grid = value; return 0; }
     if (name && !strcmp(name, "trunk_phase_delay")) { if (value < 0 || value > 4096) return fail("trunk_phase_delay out of range"); g_trunk_phase_delay = value; return 0; }
+    if (name && !strcmp(name, "trunk_delay_min_boards")) { g_trunk_delay_min_boards = value; return 0; }
     if (name && !strcmp(name, "use_graph")) { g_use_graph = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "profile_trunk")) { g_profile_trunk = value ? 1 : 0; return 0; }
     return fail("unknown option", name ? name : "(null)");

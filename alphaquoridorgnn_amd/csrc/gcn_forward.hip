@@ -1284,6 +1284,8 @@ __global__ __launch_bounds__(256, 2) void gcn_heads_mm_kernel(const float* __res
 int g_trunk_variant = 3;
 int g_trunk_phase_delay = 100;   // x 64 cycles: start offset of the second-resident workgroups, applied to launches of
                                  // >= 8192 boards (+4-11 % there; a wash at the ~2,000-board launches of the MCTS; tools/phase_scan.py)
+int g_trunk_delay_min_boards = 2048;   // launches below this many boards start all workgroups together (tools/phase_scan.py:
+                                       // +4 % at 2,048 boards, +8 % at 4,096, +15-19 % from 8,192 on the three-per-CU form)
 int g_trunk_grid = 0;      // 0 = default persistent grid; otherwise override (diagnostics)
 
 // Diagnostic: fill every CU's LDS with NaN bit patterns so that any read-before-write in a later kernel shows up
@@ -1355,17 +1357,17 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     } else if (g_trunk_variant == 5) {
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, B >= 8192 ? g_trunk_phase_delay : 0);
+        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0);
     } else if (g_trunk_variant == 4 || (g_trunk_variant == 3 && B >= 768)) {
         // three 4-wave workgroups per CU: more boards in flight per CU; wins from ~768 boards per launch (tools/phase_scan.py)
         int grid = B < 768 ? B : 768;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 3>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, B >= 8192 ? g_trunk_phase_delay / 2 : 0);
+        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 3>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, B >= g_trunk_delay_min_boards ? g_trunk_phase_delay / 2 : 0);
     } else {
         // two 8-wave workgroups per CU: shortest latency per board, best when a launch has at most ~2 boards per CU
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, B >= 8192 ? g_trunk_phase_delay : 0);
+        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0);
     }
     if (g_profile_trunk) hipEventRecord(prof_event(), st);
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;

@@ -36,7 +36,8 @@ const char* aqg_last_error(void);
 /* tuning knobs: "trunk_variant" 0/1 = exact f32-input MFMA with 1/2 workgroups per CU, 3 = all-MFMA fp16 split trunk
  * (hi*hi + hi*lo + lo*hi: fp32-equivalent products; default, form chosen per launch size), 4 / 5 / 6 = force the
  * 4-wave x 3-per-CU / 4-wave x 2-per-CU / 8-wave x 2-per-CU form;
- * "trunk_phase_delay" = start offset of the second-resident workgroups in units of 64 cycles; "use_graph" 0/1 = replay
+ * "trunk_phase_delay" = start offset of the second- / third-resident workgroups in units of 64 cycles, applied to
+ * launches of at least "trunk_delay_min_boards" boards; "use_graph" 0/1 = replay
  * a move's 3*sims+2 launches as one captured hipGraph when the stream is capturable (default 1); "profile_trunk" 0/1 = event pairs around trunk launches */
 int aqg_set_option(const char* name, int value);
 /* Measurement aid (bench.py): with option "profile_trunk" = 1 a HIP event pair is recorded around every launch of the

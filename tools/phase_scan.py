@@ -11,7 +11,8 @@ dev = _lib.require_gpu("cuda:0"); lib = _lib.load()
 model = GNNNetwork().to(dev).eval(); pk = model.packed_weights(dev)
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 _lib.set_option("trunk_variant", variant)
-for B in (256, 512, 1024, 2048, 16384, 65536):
+_lib.set_option("trunk_delay_min_boards", 0)
+for B in (256, 512, 1024, 2048, 4096, 16384, 65536):
     st = synth_states(B); pooled = torch.empty((B, 128), device=dev)
     def run():
         _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, _lib.stream_ptr(dev)), "t")
