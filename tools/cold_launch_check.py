@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Cold-launch determinism check for the GCN trunk ("LDS above 128 KB").
 
-Each fresh process uploads weights, launches the trunk 40 times on the same 300 boards (300 > 256 CUs, so some
-CUs hold a second resident workgroup) and compares every launch with the last one bit-for-bit and the first one
-with the fp64 oracle.  Run several fresh processes: the failure this guards against showed only on the first
+Each fresh process uploads weights, poisons the LDS, launches the trunk 40 times on the same 300 boards (300 > 256 CUs,
+so some CUs hold a second resident workgroup) and compares every launch with the last one bit-for-bit and the first
+one with the exact-f32 kernel (trunk_variant 0) on the same boards.  Run several fresh processes: the failure this guards against showed only on the first
 launches of a process.  Usage: cold_launch_check.py [variant=3] [processes=8]
 """
 import os
@@ -19,7 +19,6 @@ def child(variant):
     import torch
     from alphaquoridorgnn_amd import _lib
     from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
-    from oracle import gnn as og
     from tests import _util as U
     dev = _lib.require_gpu("cuda:0")
     lib = _lib.load()
@@ -27,10 +26,8 @@ def child(variant):
     g = U.golden("walk_9x9.npz")
     B = 300
     recs = g["states"][np.linspace(0, g["states"].shape[0] - 1, B).astype(int)]
-    params = og.init_params(0)
-    m = GNNNetwork()
-    m.load_state_dict({k: torch.from_numpy(x.copy()) for k, x in params.items()})
-    m = m.to("cuda").eval()
+    torch.manual_seed(0)
+    m = GNNNetwork().to("cuda").eval()
     pk = m.packed_weights(dev)
     st = torch.from_numpy(recs).to(dev)
     _lib.poison_lds(dev)
@@ -42,9 +39,11 @@ def child(variant):
         outs.append(pooled)
     torch.cuda.synchronize()
     bad = [i for i, o in enumerate(outs) if not torch.equal(o, outs[-1])]
-    ref = og.forward_states(params, recs)["pooled"]
-    err = float(np.max(np.abs(outs[0].cpu().numpy().astype(np.float64) - ref)))
-    print(f"variant {variant}: launches differing from the last: {bad[:8]} ({len(bad)}/40); first launch vs fp64 oracle max|d pooled| = {err:.3e}")
+    _lib.set_option("trunk_variant", 0)
+    ref = torch.empty((B, 128), device=dev)
+    _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(ref), None, None, None, None, _lib.stream_ptr(dev)), "trunk")
+    err = float((outs[0] - ref).abs().max())
+    print(f"variant {variant}: launches differing from the last: {bad[:8]} ({len(bad)}/40); first launch vs exact-f32 kernel max|d pooled| = {err:.3e}")
     return 1 if bad or not err < 1e-5 else 0
 
 
