@@ -115,6 +115,43 @@ def test_legal_actions_large_batch_properties(dev):
     assert e_count.numel() == 0
 
 
+def test_rules_and_mcts_on_7x7_vs_oracle(dev):
+    """A board size with no reference fixtures (the reference defines 3x3 / 5x5 / 9x9 constants only): GPU legal lists,
+    transitions, terminal flags and lock-step MCTS visit counts against the oracle on random wall-heavy play."""
+    from alphaquoridorgnn_amd import game_logic as gl
+    from alphaquoridorgnn_amd.pv_mcts import pv_mcts_policy_batch
+    from oracle import mcts as om, quoridor as oq
+    N = 7
+    rng = np.random.RandomState(7)
+    recs = []
+    for game in range(30):
+        s = oq.State(N=N)
+        for ply in range(50):
+            if s.is_done():
+                break
+            recs.append(s.rec.copy())
+            la = s.legal_actions()
+            walls = [a for a in la if a >= N * N]
+            pick = walls if (walls and rng.rand() < 0.6) else la
+            s = s.next(pick[rng.randint(len(pick))])
+    recs = np.stack(recs)
+    a, c, m = oq.legal_actions_batch(recs)
+    d = torch.from_numpy(recs).to(dev)
+    mask, order, count = gl.legal_actions_batch(d, N)
+    A = N * N + 2 * (N - 1) ** 2
+    assert np.array_equal(count.cpu().numpy(), c) and np.array_equal(mask.cpu().numpy(), m[:, :A])
+    o = order.cpu().numpy()
+    for i in range(len(recs)):
+        assert np.array_equal(o[i, :c[i]], a[i, :c[i]])
+    first = np.asarray([a[i, rng.randint(c[i])] for i in range(len(recs))], dtype=np.int32)
+    assert np.array_equal(gl.next_batch(d, torch.from_numpy(first).to(dev), N).cpu().numpy(), oq.next_batch(recs, first))
+    roots = recs[::37][:12]
+    pols = pv_mcts_policy_batch(None, roots, 1.0, sims=30, board_size=N, evaluator="fake", fake_bias=11)
+    for b in range(len(roots)):
+        ref = om.pv_mcts_policy(om.FakeModel(11), oq.State(roots[b]), 1.0, 30)
+        assert np.array_equal(np.asarray(pols[b]), np.asarray(ref))
+
+
 # ------------------------------------------------------------------ K1/K2 GNN forward
 @pytest.mark.parametrize("variant", [0, 1, 3, 4, 5, 6])
 def test_gnn_forward_boards_vs_fp64_oracle(dev, variant):

@@ -141,6 +141,35 @@ def test_training_oracle_forward_equals_gnn_oracle():
     assert [ot.lr_lambda(e) for e in (0, 49, 50, 79, 80, 99)] == [1.0, 1.0, 0.5, 0.5, 0.25, 0.25]   # train_network.py:59-65
 
 
+@pytest.mark.parametrize("N", [7, 9, 5, 3])
+def test_host_rule_header_equals_oracle_on_random_play(N):
+    """Beyond the fixtures: the header the HIP kernels compile (bitboards, interleaved flood fills, mask-algebra prefilter)
+    against the C oracle (array/queue restatement, pinned on 3x3 / 5x5 / 9x9) on fresh random play, wall-heavy, including
+    the 7x7 board for which the reference defines no constants.  Ordered legal lists, transitions, terminal flags."""
+    rng = np.random.RandomState(100 + N)
+    recs = []
+    for game in range(40):
+        s = oq.State(N=N)
+        for ply in range(60):
+            if s.is_done():
+                break
+            recs.append(s.rec.copy())
+            la = s.legal_actions()
+            walls = [a for a in la if a >= N * N]
+            pick = walls if (walls and rng.rand() < 0.6) else la
+            s = s.next(pick[rng.randint(len(pick))])
+    recs = np.stack(recs)
+    a, c, _ = oq.legal_actions_batch(recs)
+    ha, hc = U.hc_legal(N, recs)
+    assert np.array_equal(hc, c)
+    for i in range(len(recs)):
+        assert np.array_equal(ha[i, :c[i]], a[i, :c[i]]), i
+    first = np.asarray([a[i, rng.randint(c[i])] for i in range(len(recs))], dtype=np.int32)
+    assert np.array_equal(U.hc_next(N, recs, first), oq.next_batch(recs, first))
+    draw = oq.BOARDS[N][1]
+    assert np.array_equal(U.hc_status(N, recs, draw), oq.status_batch(recs, draw))
+
+
 def test_choice_index_matches_numpy():
     rng = np.random.RandomState(5)
     for _ in range(200):
