@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQG_LIB_PATH", os.path.join(_HERE, "libaqgnn_hip.so"))  # override: diagnostic builds only
 MAX_LEGAL = 136
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c = ctypes
 _vp, _i32, _f32 = _c.c_void_p, _c.c_int32, _c.c_float
@@ -29,7 +29,7 @@ class EngineStruct(_c.Structure):
                               "game_active", "game_plies", "game_result",
                               "legal_order", "legal_count", "pooled", "policy", "value",
                               "hist_state72", "hist_visits", "hist_action",
-                              "counters", "stat_leaf_evals", "stat_terminal_sims", "packed_weights")]
+                              "counters", "stat_leaf_evals", "stat_terminal_sims", "packed_weights", "gnn_workspace")]
     )
 
 
@@ -56,6 +56,8 @@ SIGNATURES = {
     "aqg_gcn_packed_floats": (_c.c_size_t, [_c.c_int]),
     "aqg_gcn_pack_weights_host": (_c.c_int, [_c.c_int, _c.POINTER(_vp), _vp]),
     "aqg_gcn_forward_boards": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "aqg_gcn_boards_any_workspace_floats": (_c.c_size_t, [_c.c_int, _c.c_int]),
+    "aqg_gcn_forward_boards_any": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _c.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aqg_gcn_forward_graph": (_c.c_int, [_c.c_int, _c.c_int, _vp, _c.c_int, _vp, _vp, _vp, _vp, _c.c_int, _vp, _vp,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aqg_engine_reset": (_c.c_int, [_c.POINTER(EngineStruct), _vp]),

@@ -1467,4 +1467,103 @@ int launch_gcn_forward_graph(int F, int A, const float* x, int num_nodes, const 
     return check_launch("gcn_heads_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------
+// boards of ANY size (3x3 .. 9x9) on plain kernels: the fused trunk above is specialised for the 9x9 board of the
+// benchmark; smaller boards (the reference's constants.py:5-20 debugging sizes) go records -> node features + normalised
+// adjacency in ELL form (<= 5 entries per node) -> 3 x (linear, ELL gather + bias + ReLU) -> mean pool -> exact heads.
+// Correctness-first, fp32 throughout.  Workspace (caller-owned): 272 floats per node.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void boards_prep_kernel(const void* __restrict__ states, int fmt, int B, float* __restrict__ x0,
+                                                          int32_t* __restrict__ ell_idx, float* __restrict__ ell_w) {
+    constexpr int V = N * N, S = N - 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * V) return;
+    const int b = i / V, t = i % V;
+    const QState s = load_state(states, fmt, b);
+    const int x = t / N, y = t % N;
+    const bool slot_ok = x < S && y < S;
+    const int slot = x * S + y;
+    float* f = x0 + (size_t)i * 6;
+    f[0] = (t == s.ppos) ? 1.f : 0.f;
+    f[1] = (float)s.pwl;
+    f[2] = (t == s.epos) ? 1.f : 0.f;
+    f[3] = (float)s.ewl;
+    f[4] = (slot_ok && ((s.hw >> slot) & 1)) ? 1.f : 0.f;
+    f[5] = (slot_ok && ((s.vw >> slot) & 1)) ? 1.f : 0.f;
+    const int ob = tile_open_bits<N>(s.hw, s.vw, t);
+    const float di = dinv_of_bits(ob);
+    const int nb[4] = {t - N, t + N, t - 1, t + 1};
+    ell_idx[(size_t)i * 5] = i;
+    ell_w[(size_t)i * 5] = di * di;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const bool open = (ob >> d) & 1;
+        ell_idx[(size_t)i * 5 + 1 + d] = open ? b * V + nb[d] : -1;
+        ell_w[(size_t)i * 5 + 1 + d] = open ? di * dinv_of_bits(tile_open_bits<N>(s.hw, s.vw, nb[d])) : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void ell_gather_kernel(const float* __restrict__ Y, int num_nodes, const int32_t* __restrict__ idx,
+                                                         const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= num_nodes) return;
+    float a0 = bias[2 * lane], a1 = bias[2 * lane + 1];
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+        const int j = idx[(size_t)n * 5 + e];
+        if (j >= 0) {
+            const float we = w[(size_t)n * 5 + e];
+            const float2 y = *reinterpret_cast<const float2*>(Y + (size_t)j * HID + 2 * lane);
+            a0 = fmaf(we, y.x, a0);
+            a1 = fmaf(we, y.y, a1);
+        }
+    }
+    *reinterpret_cast<float2*>(out + (size_t)n * HID + 2 * lane) = make_float2(fmaxf(a0, 0.f), fmaxf(a1, 0.f));
+}
+
+__global__ __launch_bounds__(128) void board_pool_kernel(const float* __restrict__ Hn, int V, float* __restrict__ pooled) {
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int i = 0; i < V; ++i) s += Hn[((size_t)b * V + i) * HID + threadIdx.x];
+    pooled[(size_t)b * HID + threadIdx.x] = s / (float)V;
+}
+
+size_t boards_any_workspace_floats(int N, int B) { return (size_t)B * N * N * 272; }
+
+int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
+                                  size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
+                                  float* value, const uint8_t* active, hipStream_t st) {
+    if (N == 9) return launch_gcn_forward_boards(N, states, fmt, B, packed, pooled, logits, policy, value_pre, value, active, st);
+    if (!(N == 3 || N == 5 || N == 7)) return fail("board_size must be 3, 5, 7 or 9");
+    if (B <= 0) return 0;
+    if (!pooled) return fail("pooled workspace is required");
+    if (!workspace || workspace_floats < boards_any_workspace_floats(N, B)) return fail("workspace too small (272 floats per node)");
+    const int V = N * N, R = B * V, A = V + 2 * (N - 1) * (N - 1);
+    float* x0 = workspace;
+    float* ell_w = x0 + (size_t)R * 6;
+    int32_t* ell_idx = reinterpret_cast<int32_t*>(ell_w + (size_t)R * 5);
+    float* work0 = reinterpret_cast<float*>(ell_idx + (size_t)R * 5);
+    float* work1 = work0 + (size_t)R * HID;
+    const dim3 pg((R + 255) / 256), lg((R + 31) / 32), gg((R + 3) / 4), blk(256);
+    switch (N) {
+        case 3: hipLaunchKernelGGL(boards_prep_kernel<3>, pg, blk, 0, st, states, fmt, B, x0, ell_idx, ell_w); break;
+        case 5: hipLaunchKernelGGL(boards_prep_kernel<5>, pg, blk, 0, st, states, fmt, B, x0, ell_idx, ell_w); break;
+        default: hipLaunchKernelGGL(boards_prep_kernel<7>, pg, blk, 0, st, states, fmt, B, x0, ell_idx, ell_w); break;
+    }
+    hipLaunchKernelGGL(graph_linear_kernel<true>, lg, blk, 0, st, (const float*)x0, 6, R, packed + PackedLayout::W1, work0);
+    hipLaunchKernelGGL(ell_gather_kernel, gg, blk, 0, st, (const float*)work0, R, (const int32_t*)ell_idx, (const float*)ell_w, packed + PackedLayout::B1, work1);
+    hipLaunchKernelGGL(graph_linear_kernel<false>, lg, blk, 0, st, (const float*)work1, HID, R, packed + PackedLayout::W2T, work0);
+    hipLaunchKernelGGL(ell_gather_kernel, gg, blk, 0, st, (const float*)work0, R, (const int32_t*)ell_idx, (const float*)ell_w, packed + PackedLayout::B2, work1);
+    hipLaunchKernelGGL(graph_linear_kernel<false>, lg, blk, 0, st, (const float*)work1, HID, R, packed + PackedLayout::W3T, work0);
+    hipLaunchKernelGGL(ell_gather_kernel, gg, blk, 0, st, (const float*)work0, R, (const int32_t*)ell_idx, (const float*)ell_w, packed + PackedLayout::B3, work1);
+    hipLaunchKernelGGL(board_pool_kernel, dim3(B), dim3(128), 0, st, (const float*)work1, V, pooled);
+    if (int r = check_launch("generic board kernels")) return r;
+    if (!logits && !policy && !value_pre && !value) return 0;
+    hipLaunchKernelGGL(gcn_heads_kernel, dim3((B + HB - 1) / HB), dim3(256), 0, st, (const float*)pooled, B, A, packed, logits, policy,
+                       value_pre, value, active);
+    return check_launch("gcn_heads_kernel");
+}
+
 }  // namespace aqg

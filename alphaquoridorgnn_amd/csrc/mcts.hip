@@ -30,6 +30,10 @@ int launch_legal_actions(int N, const void* states, int fmt, int B, uint8_t* mas
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
                               hipStream_t st);
+size_t boards_any_workspace_floats(int N, int B);
+int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
+                                  size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
+                                  float* value, const uint8_t* active, hipStream_t st);
 extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_profile_trunk;
 int g_use_graph = 1;       // aqg_set_option("use_graph", 0) forces plain launches
 
@@ -473,7 +477,7 @@ static int validate(const aqg_engine& e) {
     if (e.num_games <= 0 || e.sims <= 0) return fail("num_games and sims must be positive");
     if ((long long)e.node_cap >= (1 << 24)) return fail("node_cap must be < 2^24");
     if (e.node_cap < 1 + MAX_LEGAL) return fail("node_cap too small");
-    if (e.prior_mode == 0 && N != 9) return fail("the fused GNN evaluator is built for 9x9");
+    if (e.prior_mode == 0 && N != 9 && !e.gnn_workspace) return fail("boards other than 9x9 need gnn_workspace for the GNN evaluator");
     return 0;
 }
 
@@ -484,8 +488,10 @@ static int enqueue_sims(const aqg_engine& e, hipStream_t st) {
     for (int sim = 0; sim < e.sims; ++sim) {
         hipLaunchKernelGGL(engine_step_kernel<N>, grid, block, 0, st, e, sim > 0 ? 1 : 0, 1);
         if (e.prior_mode == 0) {
-            if (int r = launch_gcn_forward_boards(N, e.leaf_state, 1, e.num_games, e.packed_weights, e.pooled, nullptr, e.policy,
-                                                  nullptr, e.value, e.leaf_flag, st))
+            // 9x9: the fused trunk; smaller boards: plain kernels over e.gnn_workspace
+            if (int r = launch_gcn_forward_boards_any(N, e.leaf_state, 1, e.num_games, e.packed_weights, e.gnn_workspace,
+                                                      e.gnn_workspace ? boards_any_workspace_floats(N, e.num_games) : 0, e.pooled, nullptr,
+                                                      e.policy, nullptr, e.value, e.leaf_flag, st))
                 return r;
         } else {
             hipLaunchKernelGGL(engine_fake_eval_kernel<N>, grid, block, 0, st, e);

@@ -67,6 +67,8 @@ class BatchedSelfPlay:
             if model is None:
                 raise ValueError("evaluator='gnn' needs a model")
             t["packed_weights"] = model.packed_weights(dev)
+            if self.N != 9:      # smaller boards run the any-size forward, which needs a caller-owned workspace
+                t["gnn_workspace"] = z((int(self.lib.aqg_gcn_boards_any_workspace_floats(self.N, G)),), torch.float32)
         else:
             t["packed_weights"] = z((4,), torch.float32)
 
@@ -82,6 +84,7 @@ class BatchedSelfPlay:
                      "legal_count", "pooled", "policy", "value", "hist_state72", "hist_visits", "hist_action", "counters",
                      "stat_leaf_evals", "stat_terminal_sims", "packed_weights"):
             setattr(e, name, t[name].data_ptr())
+        e.gnn_workspace = t["gnn_workspace"].data_ptr() if "gnn_workspace" in t else None
         self.record_history = record_history
         self.moves_done = 0
         self.reset()

@@ -113,10 +113,18 @@ class GraphPolicyValueNetwork(nn.Module):
         value = torch.empty((B,), **f32)
         logits = torch.empty((B, A), **f32) if want_logits else None
         vpre = torch.empty((B,), **f32) if want_logits else None
-        _lib.check(lib.aqg_gcn_forward_boards(self.board_size, _lib.ptr(states72), state_fmt, B,
-                                              _lib.ptr(self.packed_weights(dev)), _lib.ptr(pooled), _lib.ptr(logits),
-                                              _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value), _lib.stream_ptr(dev)),
-                   "aqg_gcn_forward_boards")
+        if self.board_size == 9:
+            _lib.check(lib.aqg_gcn_forward_boards(self.board_size, _lib.ptr(states72), state_fmt, B,
+                                                  _lib.ptr(self.packed_weights(dev)), _lib.ptr(pooled), _lib.ptr(logits),
+                                                  _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value), _lib.stream_ptr(dev)),
+                       "aqg_gcn_forward_boards")
+        else:   # the reference's smaller boards (constants.py:5-20): plain kernels over a caller-owned workspace
+            nws = lib.aqg_gcn_boards_any_workspace_floats(self.board_size, B)
+            ws = torch.empty((max(int(nws), 1),), **f32)
+            _lib.check(lib.aqg_gcn_forward_boards_any(self.board_size, _lib.ptr(states72), state_fmt, B,
+                                                      _lib.ptr(self.packed_weights(dev)), _lib.ptr(ws), nws, _lib.ptr(pooled),
+                                                      _lib.ptr(logits), _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value),
+                                                      _lib.stream_ptr(dev)), "aqg_gcn_forward_boards_any")
         if want_logits:
             return policy, value.unsqueeze(1), logits, vpre
         return policy, value.unsqueeze(1)

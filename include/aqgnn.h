@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define AQG_MAX_LEGAL 136 /* >= 5 pawn moves + 128 wall placements */
-#define AQG_ABI_VERSION 3
+#define AQG_ABI_VERSION 4
 
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
@@ -106,6 +106,14 @@ int aqg_gcn_forward_boards(int board_size, const void* states, int state_fmt, in
  *   each node INCLUDING self loops with the gcn_norm weights already attached (built by the host wrapper
  *   from edge_index with torch ops);  graph_ptr [num_graphs+1] i32 node ranges (batch must be sorted);
  *   work0/work1 [num_nodes,128] f32 scratch. */
+/* The same forward for ANY board size 3/5/7/9: 9x9 dispatches to the fused kernels above (workspace unused), the smaller
+ * boards of the reference's constants.py:5-20 run on plain kernels (features + ELL adjacency -> linear / gather x3 -> pool
+ * -> heads) and need `workspace` of aqg_gcn_boards_any_workspace_floats(board_size, B) floats. */
+size_t aqg_gcn_boards_any_workspace_floats(int board_size, int B);
+int aqg_gcn_forward_boards_any(int board_size, const void* states, int state_fmt, int B, const float* packed, float* workspace,
+                               size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre, float* value,
+                               void* stream);
+
 int aqg_gcn_forward_graph(int num_features, int num_actions, const float* x, int num_nodes,
                           const int32_t* csr_ptr, const int32_t* csr_src, const float* csr_w,
                           const int32_t* graph_ptr, int num_graphs, const float* packed, float* work0,
@@ -144,6 +152,9 @@ typedef struct aqg_engine {
     /* per-game statistics [G] i32 (summed by the host): network evaluations, simulations that ended on a terminal node */
     int32_t* stat_leaf_evals; int32_t* stat_terminal_sims;
     const float* packed_weights;
+    /* boards other than 9x9 with prior_mode 0: workspace of the any-size forward, aqg_gcn_boards_any_workspace_floats(N, G)
+     * floats (may be NULL for 9x9 and for prior_mode 1) */
+    float* gnn_workspace;
 } aqg_engine;
 
 /* Reset all G slots to the initial position (State() game_logic.py:25-40) and mark them active. */

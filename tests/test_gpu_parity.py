@@ -202,6 +202,32 @@ def test_gnn_forward_scaled_weights(dev, variant):
     _lib.set_option("trunk_variant", 3)
 
 
+def test_gnn_small_boards_forward_and_selfplay(dev):
+    """The reference's smaller boards (constants.py:5-20) with the GNN evaluator: the any-size forward (plain kernels)
+    against the fp64 oracle on 5x5 fixtures states, and a GNN-driven 5x5 self-play generation on the engine."""
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay
+    from alphaquoridorgnn_amd.pv_network_gnn import GraphPolicyValueNetwork
+    from oracle import gnn as og, quoridor as oq
+    N, A = 5, 25 + 2 * 16
+    params = og.init_params(1, N=N)
+    model = GraphPolicyValueNetwork(6, 128, 3, A, board_size=N)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    model = model.to(dev).eval()
+    g = U.golden("walk_5x5.npz")
+    recs = g["states"][::23][:150]
+    ref = og.forward_states(params, recs)
+    policy, value, logits, vpre = model.forward_states(torch.from_numpy(recs).to(dev), want_logits=True)
+    np.testing.assert_allclose(logits.cpu().numpy(), ref["logits"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(vpre.cpu().numpy(), ref["value_pre"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(policy.cpu().numpy(), ref["policy"], atol=1e-6, rtol=1e-4)
+    eng = BatchedSelfPlay(model, num_games=40, sims=10, board_size=N, seed=2)
+    c = eng.play_generation()
+    assert c["active"] == 0 and c["finished"] == 40
+    st, vis, z = (x.cpu().numpy() for x in eng.history_tensors())
+    assert st.shape[0] == vis.shape[0] == z.shape[0] > 40 and (vis.sum(1) == 9).all()
+    assert np.array_equal(st[0], oq.init_record(N))
+
+
 def test_gnn_forward_generic_graph(dev):
     """forward(x, edge_index, batch) on (a) the board graphs and (b) an arbitrary ragged graph batch."""
     from oracle import gnn as og

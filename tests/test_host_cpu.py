@@ -28,7 +28,7 @@ def test_capi_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} not bound in _lib.SIGNATURES"
     assert lib.aqg_abi_version() == _lib.ABI_VERSION
     assert lib.aqg_gcn_packed_floats(9) > 64082          # all 64,082 parameters + padding + fragment copies
-    assert ctypes.sizeof(_lib.EngineStruct) == 9 * 4 + 2 * 4 + 4 + 22 * 8   # 11 scalars (+4 pad) + 22 pointers
+    assert ctypes.sizeof(_lib.EngineStruct) == 9 * 4 + 2 * 4 + 4 + 23 * 8   # 11 scalars (+4 pad) + 23 pointers
     assert ctypes.sizeof(_lib.TrainStruct) == 8 * 4 + 4 * 14 * 8 + 20 * 8      # aqg_train: 8 scalars, 4 x 14 + 20 pointers
 
 
