@@ -226,6 +226,19 @@ def test_gnn_small_boards_forward_and_selfplay(dev):
     st, vis, z = (x.cpu().numpy() for x in eng.history_tensors())
     assert st.shape[0] == vis.shape[0] == z.shape[0] > 40 and (vis.sum(1) == 9).all()
     assert np.array_equal(st[0], oq.init_record(N))
+    # ... and the training step on that board: gradients against fp64 autograd
+    from alphaquoridorgnn_amd.train_network import GNNTrainer
+    from oracle import train as ot
+    rng = np.random.RandomState(4)
+    tr_recs = recs[:24]
+    pi = rng.rand(24, A).astype(np.float32)
+    pi /= pi.sum(1, keepdims=True)
+    zt = rng.choice([-1.0, 0.0, 1.0], 24).astype(np.float32)
+    tr = GNNTrainer(model, max_batch=24)
+    tr.step(torch.from_numpy(tr_recs), torch.from_numpy(pi), torch.from_numpy(zt), update=False)
+    refg = ot.train_steps(params, [(tr_recs, pi.astype(np.float64), zt.astype(np.float64))])[0]["grads"]
+    for k, gt in zip(og.KEYS, tr.grads):
+        assert np.abs(gt.cpu().numpy().astype(np.float64) - refg[k]).max() <= 2e-5 * np.abs(refg[k]).max() + 1e-7, k
 
 
 def test_gnn_forward_generic_graph(dev):
