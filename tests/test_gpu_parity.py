@@ -624,6 +624,31 @@ def test_train_cycle_one_iteration(dev, tmp_path, monkeypatch):
     assert len(list((tmp_path / "data").glob("*.history"))) == 1
 
 
+_CYCLE_5X5 = r'''
+import os, sys
+sys.path.insert(0, os.environ["AQG_REPO"])
+from alphaquoridorgnn_amd import constants, pv_mcts, self_play as sp, train_network as tn, evaluate_network as en, train_cycle as tc
+assert constants.BOARD_SIZE == 5 and constants.NUM_WALLS == 2 and constants.NUM_PLIES_FOR_DRAW == 28
+pv_mcts.PV_EVALUATE_COUNT = 8
+sp.SP_GAME_COUNT = 12
+tn.NUM_EPOCH = 2
+en.EN_GAME_COUNT = 4
+print("PROMOTED", tc.train_cycle(num_cycles=1))
+'''
+
+
+def test_train_cycle_on_5x5_board(dev, tmp_path):
+    """The whole learning loop with the module constants switched to the reference's 5x5 block (AQG_BOARD_SIZE=5, the
+    counterpart of editing constants.py:13-16): self-play, training and evaluation all run the GNN on the small board."""
+    import subprocess
+    (tmp_path / "cycle.py").write_text(_CYCLE_5X5)
+    env = dict(os.environ, AQG_REPO=REPO, AQG_BOARD_SIZE="5")
+    r = subprocess.run([sys.executable, str(tmp_path / "cycle.py")], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "PROMOTED [" in r.stdout
+    assert (tmp_path / "models" / "GNN" / "5x5" / "latest.pth").exists() and len(list((tmp_path / "data").glob("*.history"))) == 1
+
+
 # ------------------------------------------------------------------ drop-in surface (reference-shaped calls)
 def test_dropin_surface_play_and_policy(dev, tmp_path, monkeypatch):
     """The reference's call surface end to end on the GPU: pv_mcts_policy / pv_mcts_action on a State, self_play.play()
