@@ -946,7 +946,8 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         AQG_STAMP_AT(15)
         adj_store<JT, true>(sm, out, bias4, wave, lane, pooled + (size_t)b * HID);
         rec0 = nrec0; rec1 = nrec1;
-        __syncthreads();                                                    // AF / X0 / dinv / planes are free for the next board
+        if (bn < B) __syncthreads();                                        // AF / X0 / dinv / planes are free for the next board
+                                                                            // (bn is workgroup-uniform; the last board needs no barrier)
         AQG_STAMP_AT(5)
 #ifdef AQG_STAMP
         ++st_n;
