@@ -11,7 +11,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQG_LIB_PATH", os.path.join(_HERE, "libaqgnn_hip.so"))  # override: diagnostic builds only
 MAX_LEGAL = 136
-ABI_VERSION = 4
+GNN_EXACT_F32 = 1        # AQG_GNN_EXACT_F32 (include/aqgnn.h)
+ABI_VERSION = 5
 
 _c = ctypes
 _vp, _i32, _f32 = _c.c_void_p, _c.c_int32, _c.c_float
@@ -20,13 +21,13 @@ _vp, _i32, _f32 = _c.c_void_p, _c.c_int32, _c.c_float
 class EngineStruct(_c.Structure):
     """Mirror of `struct aqg_engine` (include/aqgnn.h)."""
     _fields_ = (
-        [(n, _i32) for n in ("board_size", "num_walls", "plies_for_draw", "num_games", "sims", "node_cap",
-                             "max_plies", "prior_mode", "fake_bias")]
+        [(n, _i32) for n in ("board_size", "num_walls", "plies_for_draw", "num_games", "quota", "sims", "node_cap",
+                             "max_plies", "prior_mode", "fake_bias", "gnn_flags")]
         + [("c_puct", _f32), ("temperature", _f32)]
         + [(n, _vp) for n in ("node_rec",
                               "node_count", "root_state", "path", "path_len",
                               "leaf_flag", "leaf_state",
-                              "game_active", "game_plies", "game_result",
+                              "game_active", "slot_game", "game_plies", "game_result", "game_done", "game_slot", "game_first_move",
                               "legal_order", "legal_count", "pooled", "policy", "value",
                               "hist_state72", "hist_visits", "hist_action",
                               "counters", "stat_leaf_evals", "stat_terminal_sims", "packed_weights", "gnn_workspace")]
@@ -55,14 +56,18 @@ SIGNATURES = {
     "aqg_state_status": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp]),
     "aqg_gcn_packed_floats": (_c.c_size_t, [_c.c_int]),
     "aqg_gcn_pack_weights_host": (_c.c_int, [_c.c_int, _c.POINTER(_vp), _vp]),
-    "aqg_gcn_forward_boards": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "aqg_gcn_forward_boards": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "aqg_gcn_boards_any_workspace_floats": (_c.c_size_t, [_c.c_int, _c.c_int]),
-    "aqg_gcn_forward_boards_any": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _c.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "aqg_gcn_forward_boards_any": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _c.c_size_t, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "aqg_gcn_forward_graph": (_c.c_int, [_c.c_int, _c.c_int, _vp, _c.c_int, _vp, _vp, _vp, _vp, _c.c_int, _vp, _vp,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aqg_engine_reset": (_c.c_int, [_c.POINTER(EngineStruct), _vp]),
     "aqg_engine_move": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp]),
     "aqg_engine_search": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp]),
+    "aqg_engine_begin_move": (_c.c_int, [_c.POINTER(EngineStruct), _vp]),
+    "aqg_engine_step": (_c.c_int, [_c.POINTER(EngineStruct), _c.c_int, _c.c_int, _vp]),
+    "aqg_engine_finish_move": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp]),
+    "aqg_engine_set_roots": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp]),
     "aqg_engine_root_visits": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp, _vp, _vp]),
     "aqg_gcn_train_step": (_c.c_int, [_c.POINTER(TrainStruct), _vp, _vp, _vp, _c.c_int, _vp]),
 }

@@ -10,6 +10,8 @@ extern int g_trunk_grid;
 extern int g_trunk_phase_delay;
 extern int g_trunk_delay_min_boards;
 extern int g_use_graph;
+extern int g_step_variant;
+extern int g_step_fast_depth;
 int profile_collect(double* total_ms, long long* launches, long long* boards, int reset);
 int launch_poison_lds(hipStream_t st);
 
@@ -21,16 +23,20 @@ int launch_state_next(int N, const uint8_t* in, const int32_t* actions, int B, u
 int launch_state_status(int N, const uint8_t* in, int B, int draw, uint8_t* flags, hipStream_t st);
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
-                              hipStream_t st);
+                              int flags, hipStream_t st);
 size_t boards_any_workspace_floats(int N, int B);
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
-                                  float* value, const uint8_t* active, hipStream_t st);
+                                  float* value, const uint8_t* active, int flags, hipStream_t st);
 int launch_gcn_forward_graph(int F, int A, const float* x, int num_nodes, const int32_t* csr_ptr, const int32_t* csr_src,
                              const float* csr_w, const int32_t* graph_ptr, int num_graphs, const float* packed,
                              float* work0, float* work1, float* pooled, float* logits, float* policy, float* value_pre,
                              float* value, hipStream_t st);
 int engine_reset(const aqg_engine& e, hipStream_t st);
+int engine_begin_move(const aqg_engine& e, hipStream_t st);
+int engine_step(const aqg_engine& e, int do_expand, int do_select, hipStream_t st);
+int engine_finish_move(const aqg_engine& e, const double* uniforms, hipStream_t st);
+int engine_set_roots(const aqg_engine& e, const uint8_t* roots72, hipStream_t st);
 int engine_move(const aqg_engine& e, const double* uniforms, hipStream_t st);
 int engine_search(const aqg_engine& e, const uint8_t* roots72, hipStream_t st);
 int engine_root_visits(const aqg_engine& e, int32_t* visits, uint8_t* actions, int32_t* count, hipStream_t st);
@@ -49,6 +55,8 @@ int aqg_set_option(const char* name, int value) {
     if (name && !strcmp(name, "trunk_grid")) { g_trunk_grid = value; return 0; }
     if (name && !strcmp(name, "trunk_phase_delay")) { if (value < 0 || value > 4096) return fail("trunk_phase_delay out of range"); g_trunk_phase_delay = value; return 0; }
     if (name && !strcmp(name, "trunk_delay_min_boards")) { g_trunk_delay_min_boards = value; return 0; }
+    if (name && !strcmp(name, "step_variant")) { g_step_variant = value ? 1 : 0; return 0; }
+    if (name && !strcmp(name, "step_fast_depth")) { if (value < 0 || value > 61) return fail("step_fast_depth must be 0..61"); g_step_fast_depth = value; return 0; }
     if (name && !strcmp(name, "use_graph")) { g_use_graph = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "profile_trunk")) { g_profile_trunk = value ? 1 : 0; return 0; }
     return fail("unknown option", name ? name : "(null)");
@@ -85,22 +93,22 @@ int aqg_gcn_pack_weights_host(int board_size, const float* const* tensors_host, 
 }
 
 int aqg_gcn_forward_boards(int board_size, const void* states, int state_fmt, int B, const float* packed, float* pooled,
-                           float* logits, float* policy, float* value_pre, float* value, void* stream) {
+                           float* logits, float* policy, float* value_pre, float* value, int flags, void* stream) {
     if (B < 0 || (B > 0 && (!states || !packed))) return fail("aqg_gcn_forward_boards: bad arguments");
     if (state_fmt != 0 && state_fmt != 1) return fail("aqg_gcn_forward_boards: state_fmt must be 0 or 1");
     return launch_gcn_forward_boards(board_size, states, state_fmt, B, packed, pooled, logits, policy, value_pre, value, nullptr,
-                                     (hipStream_t)stream);
+                                     flags, (hipStream_t)stream);
 }
 
 size_t aqg_gcn_boards_any_workspace_floats(int board_size, int B) { return B > 0 ? boards_any_workspace_floats(board_size, B) : 0; }
 
 int aqg_gcn_forward_boards_any(int board_size, const void* states, int state_fmt, int B, const float* packed, float* workspace,
                                size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre, float* value,
-                               void* stream) {
+                               int flags, void* stream) {
     if (B < 0 || (B > 0 && (!states || !packed))) return fail("aqg_gcn_forward_boards_any: bad arguments");
     if (state_fmt != 0 && state_fmt != 1) return fail("aqg_gcn_forward_boards_any: state_fmt must be 0 or 1");
     return launch_gcn_forward_boards_any(board_size, states, state_fmt, B, packed, workspace, workspace_floats, pooled, logits, policy,
-                                         value_pre, value, nullptr, (hipStream_t)stream);
+                                         value_pre, value, nullptr, flags, (hipStream_t)stream);
 }
 
 int aqg_gcn_forward_graph(int num_features, int num_actions, const float* x, int num_nodes, const int32_t* csr_ptr,
@@ -120,6 +128,22 @@ int aqg_engine_reset(const aqg_engine* e, void* stream) {
 int aqg_engine_move(const aqg_engine* e, const double* uniforms, void* stream) {
     if (!e || !uniforms) return fail("aqg_engine_move: null argument");
     return engine_move(*e, uniforms, (hipStream_t)stream);
+}
+int aqg_engine_begin_move(const aqg_engine* e, void* stream) {
+    if (!e) return fail("aqg_engine_begin_move: null engine");
+    return engine_begin_move(*e, (hipStream_t)stream);
+}
+int aqg_engine_step(const aqg_engine* e, int do_expand, int do_select, void* stream) {
+    if (!e) return fail("aqg_engine_step: null engine");
+    return engine_step(*e, do_expand ? 1 : 0, do_select ? 1 : 0, (hipStream_t)stream);
+}
+int aqg_engine_finish_move(const aqg_engine* e, const double* uniforms, void* stream) {
+    if (!e || !uniforms) return fail("aqg_engine_finish_move: null argument");
+    return engine_finish_move(*e, uniforms, (hipStream_t)stream);
+}
+int aqg_engine_set_roots(const aqg_engine* e, const uint8_t* root_states72, void* stream) {
+    if (!e || !root_states72) return fail("aqg_engine_set_roots: null argument");
+    return engine_set_roots(*e, root_states72, (hipStream_t)stream);
 }
 int aqg_engine_search(const aqg_engine* e, const uint8_t* root_states72, void* stream) {
     if (!e || !root_states72) return fail("aqg_engine_search: null argument");

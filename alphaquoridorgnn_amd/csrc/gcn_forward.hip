@@ -59,8 +59,16 @@ struct PackedLayout {
     // k-slot (q, e) <-> hidden unit 32*kb + 16*(e >> 2) + 4*q + (e & 3): the order the layer-1 accumulators hold them)
     static constexpr size_t WHH1 = WH1 + 4 * 2 * 64 * 4;
     static constexpr size_t WHP2 = WHH1 + 2 * 8 * 4 * 64 * 4;
-    static constexpr size_t TOTAL = WHP2 + 2 * 14 * 2 * 64 * 4;
+    // aggregation accumulator init of the default trunk: TB[layer 3][deg-1 5][HID] = CQ * b_layer[f] * sqrt(deg)
+    // (the bias of a node with `deg` neighbours incl. itself, pre-divided by its D^-1/2 factor; see the trunk comment)
+    static constexpr size_t TB = WHP2 + 2 * 14 * 2 * 64 * 4;
+    static constexpr size_t TOTAL = TB + 3 * 5 * HID;
 };
+
+// Scale of the activation image of the default trunk: the planes hold Q = CQ * relu(...) / D^-1/2.  CQ = 15/16 makes
+// CQ / deg exact in fp16 for every degree 1..5 (0.9375, 0.46875, 0.3125, 0.234375, 0.1875): the normalised adjacency
+// becomes an EXACT fp16 matrix and no activation is ever multiplied by an irrational D^-1/2 factor on the vector unit.
+constexpr double CQ = 15.0 / 16.0;
 
 size_t packed_floats() { return PackedLayout::TOTAL; }
 
@@ -105,9 +113,9 @@ int pack_weights_host(int N, const float* const* t, float* out) {
                     for (int lane = 0; lane < 64; ++lane)
                         for (int d = 0; d < 4; ++d) {
                             const int c = lane & 15, q = lane >> 4, n = 32 * w + 16 * j + c;
-                            uint16_t a[2], b[2];
-                            split2(W[n * HID + 32 * kb + 8 * q + 2 * d], a);
-                            split2(W[n * HID + 32 * kb + 8 * q + 2 * d + 1], b);
+                            uint16_t a[2], b[2];                  // layers 2, 3 see the planes' scale: W / CQ
+                            split2((float)((double)W[n * HID + 32 * kb + 8 * q + 2 * d] / CQ), a);
+                            split2((float)((double)W[n * HID + 32 * kb + 8 * q + 2 * d + 1] / CQ), b);
                             for (int pl = 0; pl < 2; ++pl) {
                                 const size_t o = (((((size_t)pl * 4 + w) * 2 + j) * 4 + kb) * 64 + lane) * 4 + d;
                                 dst[o] = (uint32_t)a[pl] | ((uint32_t)b[pl] << 16);
@@ -168,6 +176,10 @@ int pack_weights_host(int N, const float* const* t, float* out) {
                             d2[((((size_t)pl * 14 + at) * 2 + kb) * 64 + lane) * 4 + d] = (uint32_t)h[0][pl] | ((uint32_t)h[1][pl] << 16);
                     }
     }
+    for (int L = 0; L < 3; ++L)
+        for (int deg = 1; deg <= 5; ++deg)
+            for (int f = 0; f < HID; ++f)
+                out[PackedLayout::TB + ((size_t)L * 5 + (deg - 1)) * HID + f] = (float)(CQ * (double)t[2 * L + 1][f] * sqrt((double)deg));
     for (int u = 0; u < HID / 2; ++u)
         for (int k = 0; k < HID; ++k) {
             out[PackedLayout::HW1T + k * HID + u] = t[6][u * HID + k];
@@ -605,13 +617,16 @@ constexpr unsigned int AF_NT_PACK = 0u | (1u << 3) | (1u << 6) | (2u << 9) | (2u
 constexpr int af_kb(int blk) { return (AF_KB_PACK >> (2 * blk)) & 3; }
 constexpr int af_nt(int blk) { return (AF_NT_PACK >> (3 * blk)) & 7; }
 
+template <int NWV>
 struct alignas(16) TrunkSmemM {
-    alignas(16) unsigned char P[2][PPLANE];            // fp16 hi / lo planes of the activation image [node][feature]
-    alignas(16) unsigned int AF[AF_BLOCKS][64][4];     // (A + I) B fragments of this board (fp16 0 / 1)
-    alignas(16) unsigned int X0[96][4];                // node features as 8 fp16 (6 used); rows 81..95 stay zero
-    alignas(16) float dinv[96];                        // deg^-1/2 per node; entries 81..95 stay zero
+    alignas(16) unsigned char P[2][PPLANE];            // fp16 hi / lo planes of the activation image [node][feature] (scale CQ / D^-1/2)
+    alignas(16) unsigned int AF[AF_BLOCKS][64][4];     // B fragments of (A + I) diag(CQ / deg) of this board (fp16, exact)
+    alignas(16) unsigned int X0[81][4];                // node features as 8 fp16 (6 used)
+    alignas(16) float sqd[96];                         // deg^1/2 per node; entries 81..95 stay zero
+    alignas(16) float dnv[96];                         // deg^-1/2 per node; entries 81..95 stay zero
+    alignas(16) unsigned short degv[NWV][NWV == 4 ? 3 : 2][32];   // per wave and block slot: fp16 CQ / deg of the 32 nodes of a k block
 };
-static_assert(3 * sizeof(TrunkSmemM) <= 160 * 1024, "three 4-wave workgroups per CU");
+static_assert(2 * sizeof(TrunkSmemM<8>) <= 160 * 1024, "two 8-wave workgroups per CU");
 
 __device__ __forceinline__ float row16_sum(float x) {     // sum over the 16 lanes of a DPP row, result in every lane
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));   // row_ror:8
@@ -631,13 +646,44 @@ __device__ __forceinline__ u32x4 load_frag16(__amdgpu_buffer_rsrc_t rs, int lane
     return __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, byte_off, 0);
 }
 
+// Low part of the fp16 split of two f32 values whose high parts are the halves of h01: f16(x0 - h01.lo) | f16(x1 - h01.hi) << 16.
+// v_fma_mix{lo,hi}_f16 reads the fp16 half directly and rounds the f32 difference (exact: h is x rounded to 11 bits) to
+// fp16 in ONE instruction per value, where convert-back / subtract / convert-pair took 2.5.  hipcc does not select the
+// mix forms for this pattern, hence the asm; its result must not feed an MFMA without the wait states of split_fence().
+__device__ __forceinline__ unsigned int lo_pair(unsigned int h01, float x0, float x1) {
+    unsigned int d;
+    // (-1 comes in a scalar register: how a floating-point inline constant is widened for a source whose op_sel_hi bit says
+    // "f32" is not something to depend on)
+    asm("v_fma_mixlo_f16 %0, %1, %4, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, %4, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(d) : "v"(h01), "v"(x0), "v"(x1), "s"(-1.0f));
+    return d;
+}
+// relu on the BIT PATTERN: max(int(x), 0) -- negative floats (sign bit set) are negative integers, non-negative floats order
+// like their bit patterns -- optionally saturating at the largest finite fp16 (0x477FE000 = 65504.0f).  One v_max_i32 /
+// v_med3_i32, and unlike fmaxf() on an MFMA result no canonicalising v_max on top; unlike an asm v_max_f32 the compiler SEES
+// it, so the matrix pipe's write-back latency in front of this first reader is padded by the compiler, wherever it schedules it.
+__device__ __forceinline__ float relu_sat16(float x) {
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, min(max(i, 0), 0x477FE000));
+}
+__device__ __forceinline__ float relu_f(float x) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0)); }
+// VALU write inside an asm statement -> MFMA operand: hipcc pads nothing for asm (guide 5.7 item 2); the fragments pass
+// through this statement (two wait states) before their first MFMA.
+__device__ __forceinline__ void split_fence(u32x4& a, u32x4& b, u32x4& c) {
+    asm volatile("s_nop 3" : "+v"(a), "+v"(b), "+v"(c));
+}
+// (The opposite direction -- an MFMA result first read INSIDE an asm statement -- has the same blind spot: the first version of
+// this kernel did its relu in asm and was wrong by different amounts in each of its three forms, depending on what the scheduler
+// happened to put between the last MFMA and the asm.  Every first reader of an accumulator is compiler-visible code now.)
+
 // A wave owns JT 16-column feature tiles: JT = 2 -> 4 waves per board, JT = 1 -> 8 waves per board.
 // fp16 planes of four consecutive features of one node: hi (11 bits) + lo (next 11 bits) = 22 mantissa bits
-__device__ __forceinline__ void store_split4(TrunkSmemM& sm, int off, const f32x4 v) {
+template <int NWV>
+__device__ __forceinline__ void store_split4(TrunkSmemM<NWV>& sm, int off, const f32x4 v) {
     const unsigned int h01 = cvt_pk_f16(v[0], v[1]), h23 = cvt_pk_f16(v[2], v[3]);
-    const f32x4 r1 = v - f16_pairs_to_f32(h01, h23);
     *reinterpret_cast<u32x2*>(&sm.P[0][off]) = (u32x2){h01, h23};
-    *reinterpret_cast<u32x2*>(&sm.P[1][off]) = (u32x2){cvt_pk_f16(r1[0], r1[1]), cvt_pk_f16(r1[2], r1[3])};
+    *reinterpret_cast<u32x2*>(&sm.P[1][off]) = (u32x2){lo_pair(h01, v[0], v[1]), lo_pair(h23, v[2], v[3])};
 }
 
 template <int JT>
@@ -651,15 +697,22 @@ __device__ __forceinline__ void load_bfrag_mm(u32x4 (&Bf)[2][JT][4], __amdgpu_bu
             for (int kb = 0; kb < 4; ++kb) Bf[pl][j][kb] = load_frag16(rs, lane * 16, base + (pl * (8 * 4 * 64) + (j * 4 + kb) * 64) * 16);
 }
 
-// Z = H W for this wave's columns: six 16-row tiles (tile 5 = row 80 repeated) x four 32-deep k blocks, A fragments
-// double-buffered from the planes, three fp16 terms per block (smallest first).
+// fp16 hi / lo aggregation fragments of one finished 16-node tile m of U (accumulator layout: lane = feature column, 4
+// consecutive nodes): dwords 2 (m & 1), 2 (m & 1) + 1 of k block m >> 1.  `piece` 0 = the two hi dwords, 1 / 2 = one lo dword each,
+// so that the three pieces can be spread over the MFMA groups of the NEXT tile.
+__device__ __forceinline__ void split_tile_piece(const f32x4 z, int m, int piece, u32x4 (&zh)[3], u32x4 (&zl)[3]) {
+    const int kb = m >> 1, d = 2 * (m & 1);
+    if (piece == 0) { zh[kb][d] = cvt_pk_f16(z[0], z[1]); zh[kb][d + 1] = cvt_pk_f16(z[2], z[3]); }
+    else if (piece == 1) zl[kb][d] = lo_pair(zh[kb][d], z[0], z[1]);
+    else zl[kb][d + 1] = lo_pair(zh[kb][d + 1], z[2], z[3]);
+}
+
+// U = Q W~ for this wave's columns: six 16-row tiles (tile 5 = row 80 repeated) x four 32-deep k blocks, A fragments
+// double-buffered from the planes, three fp16 terms per block (smallest first).  The fp16 split of tile m - 1 (six vector
+// instructions per feature tile) is issued between the MFMA groups of tile m: it costs no time of its own.
 template <int JT>
-__device__ __forceinline__ void stripe_matmul_mm(const TrunkSmemM& sm, const u32x4 (&Bf)[2][JT][4], int lane, f32x4 (&acc)[6][JT]) {
+__device__ __forceinline__ void linear_split(const TrunkSmemM<8 / JT>& sm, const u32x4 (&Bf)[2][JT][4], int lane, u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3]) {
     const int c = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int m = 0; m < 6; ++m)
-#pragma unroll
-        for (int j = 0; j < JT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     u32x4 cur[2], nxt[2];
     auto frag_off = [&](int step) -> int {                  // step = m*4 + kb
         const int m = step >> 2, kb = step & 3;
@@ -671,6 +724,7 @@ __device__ __forceinline__ void stripe_matmul_mm(const TrunkSmemM& sm, const u32
         cur[0] = *reinterpret_cast<const u32x4*>(&sm.P[0][o]);
         cur[1] = *reinterpret_cast<const u32x4*>(&sm.P[1][o]);
     }
+    f32x4 acc[JT], done[JT];
 #pragma unroll
     for (int step = 0; step < 24; ++step) {
         const int m = step >> 2, kb = step & 3;
@@ -682,98 +736,106 @@ __device__ __forceinline__ void stripe_matmul_mm(const TrunkSmemM& sm, const u32
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
-            f32x4 a = acc[m][j];
+            f32x4 a = kb == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[j];
             a = mfma_f16(cur[1], Bf[0][j][kb], a);
             a = mfma_f16(cur[0], Bf[1][j][kb], a);
             a = mfma_f16(cur[0], Bf[0][j][kb], a);
-            acc[m][j] = a;
+            acc[j] = a;
+            if (m > 0 && kb < 3) split_tile_piece(done[j], m - 1, kb, zh[j], zl[j]);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (step < 23) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
-    }
-}
-
-// aggregation part 1 (touches no plane bytes): Z' = dinv (.) Z -> fp16 hi/lo A fragments -> Y^T = Z'^T (A + I)
-template <int JT>
-__device__ __forceinline__ void adj_matmul(const TrunkSmemM& sm, const f32x4 (&acc)[6][JT], int lane, f32x4 (&out)[6][JT]) {
-    const int q = lane >> 4;
-    // all ten adjacency fragments are requested first: their LDS latency hides under the split arithmetic below (requested
-    // one by one next to their MFMAs, each cost a full lgkmcnt(0) round trip)
-    u32x4 af[AF_BLOCKS];
+        if (kb == 3) {
 #pragma unroll
-    for (int blk = 0; blk < AF_BLOCKS; ++blk) af[blk] = *reinterpret_cast<const u32x4*>(&sm.AF[blk][lane][0]);
-    f32x4 d4[6];
-#pragma unroll
-    for (int m = 0; m < 6; ++m) d4[m] = *reinterpret_cast<const f32x4*>(&sm.dinv[16 * m + 4 * q]);   // 0 beyond node 80: clears tile 5's duplicate rows
-    // one feature tile at a time (its accumulators die as its fragments are built: the 4-wave form fits 168 registers)
-#pragma unroll
-    for (int j = 0; j < JT; ++j) {
-        u32x4 zh[3], zl[3];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            const f32x4 z = acc[m][j] * d4[m];
-            const unsigned int h01 = cvt_pk_f16(z[0], z[1]), h23 = cvt_pk_f16(z[2], z[3]);
-            const f32x4 r = z - f16_pairs_to_f32(h01, h23);
-            zh[m >> 1][2 * (m & 1)] = h01; zh[m >> 1][2 * (m & 1) + 1] = h23;
-            zl[m >> 1][2 * (m & 1)] = cvt_pk_f16(r[0], r[1]); zl[m >> 1][2 * (m & 1) + 1] = cvt_pk_f16(r[2], r[3]);
+            for (int j = 0; j < JT; ++j) done[j] = acc[j];
         }
-#pragma unroll
-        for (int nt = 0; nt < 6; ++nt) out[nt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // two passes (lo term, then hi term) over the blocks in an order that never puts two MFMAs of one accumulator
-        // back to back: node tiles 0,1,2,3,4,5 then 1,2,3,4
-        constexpr int ORDER[AF_BLOCKS] = {0, 1, 3, 5, 7, 9, 2, 4, 6, 8};
-#pragma unroll
-        for (int term = 0; term < 2; ++term)
-#pragma unroll
-            for (int i = 0; i < AF_BLOCKS; ++i) {
-                const int blk = ORDER[i], kb = af_kb(blk), nt = af_nt(blk);
-                out[nt][j] = mfma_f16(term == 0 ? zl[kb] : zh[kb], af[blk], out[nt][j]);
-            }
     }
-}
-
-// this lane's 4 bias values per feature tile, straight from the packed buffer (requested before the aggregation MFMAs,
-// consumed after them)
-template <int JT>
-__device__ __forceinline__ void load_bias(f32x4 (&bias4)[JT], __amdgpu_buffer_rsrc_t rs, size_t region, int wave, int lane) {
 #pragma unroll
     for (int j = 0; j < JT; ++j)
-        bias4[j] = __builtin_bit_cast(f32x4, load_frag16(rs, (lane >> 4) * 16, (int)(region * sizeof(float)) + 64 * (JT * wave + j)));
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece) split_tile_piece(done[j], 5, piece, zh[j], zl[j]);
 }
 
-// aggregation part 2: H' = relu(dinv_n * Y + b) -> split planes (lane = node, 4 consecutive features), or the mean pool
+// The aggregation accumulators start from the bias: out[nt][j] = TB[layer][deg(node) - 1][this lane's 4 features] = CQ b sqrt(deg),
+// so that relu(out) IS the next plane image -- no multiply, no add on the vector unit.  `toff` packs (deg - 1) * 512 + 16 q per
+// node tile of this lane, 16 bits each.  Requested a whole phase ahead of their use (before the linear map).
+template <int JT>
+__device__ __forceinline__ void request_bias(f32x4 (&out)[6][JT], __amdgpu_buffer_rsrc_t rs, int layer, const int (&toff)[3], int wave) {
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) {
+            const int vo = (nt & 1) ? (int)((unsigned)toff[nt >> 1] >> 16) : (toff[nt >> 1] & 0xFFFF);
+            out[nt][j] = __builtin_bit_cast(f32x4, load_frag16(rs, vo, (int)((PackedLayout::TB + (size_t)layer * 5 * HID) * sizeof(float)) + 64 * (JT * wave + j)));
+        }
+}
+
+// Aggregation + epilogue, node tile by node tile:  V^T = U^T (A + I) diag(CQ / deg) on top of the bias rows, then
+// Q = relu(V) -> split planes (lane = node, 4 consecutive features), or the mean pool of D^-1/2 Q / CQ for the last layer.
+// The blocks of a node tile are consecutive (a dependent 16x16x32 chain issues at the full rate), so tile nt is complete while
+// tile nt + 1 is still on the matrix pipe: its relu / split / stores are vector and LDS work issued under those MFMAs.
+// (No plane byte is read here: the caller has passed the barrier behind the linear map, the stores are free to go.)
 template <int JT, bool LAST>
-__device__ __forceinline__ void adj_store(TrunkSmemM& sm, const f32x4 (&out)[6][JT], const f32x4 (&bias4)[JT], int wave, int lane,
-                                          float* __restrict__ pooled_out) {
+__device__ __forceinline__ void aggregate_store(TrunkSmemM<8 / JT>& sm, u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], f32x4 (&out)[6][JT], int wave, int lane,
+                                                __amdgpu_buffer_rsrc_t pooled_rs, int pooled_soff) {
+    constexpr int AHEAD = 3;                                   // adjacency fragments in flight (4 registers each)
     const int c = lane & 15, q = lane >> 4;
     const int col0 = 16 * JT * wave + 4 * q;
+    u32x4 af[AF_BLOCKS];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) af[i] = *reinterpret_cast<const u32x4*>(&sm.AF[i][lane][0]);
+#pragma unroll
+    for (int j = 0; j < JT; ++j) split_fence(zl[j][0], zl[j][1], zl[j][2]);
     f32x4 sum[JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) sum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int nt = 0; nt < 6; ++nt) {
+    auto epilogue = [&](int nt) {
         const int node = 16 * nt + c;
-        const float dn = sm.dinv[node];
         const bool live = (nt < 5) || (c == 0);                              // node < 81
+        float dn = 0.f;
+        if (LAST) dn = sm.dnv[node];
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
-            f32x4 v = out[nt][j] * dn + bias4[j];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            f32x4 v = out[nt][j];
             if (LAST) {
-                if (live) sum[j] += v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
+                if (live) sum[j] += v * dn;
             } else {
+                // relu, saturating at the largest finite fp16: an overflowing activation stays a (wrong) finite number
+                // instead of becoming inf - inf = NaN that the next relu would silently turn into 0.  The host checks
+                // every weight set against the exact-f32 trunk before it trusts this kernel (pv_network_gnn.packed_weights).
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = relu_sat16(v[e]);
                 if (live) store_split4(sm, plane_off(node, (col0 + 16 * j) >> 3) + ((2 * (col0 + 16 * j)) & 15), v);
             }
         }
+    };
+    // blocks are numbered in node-tile order already: kb = {0,0,1,0,1,1,2,1,2,2}, nt = {0,1,1,2,2,3,3,4,4,5}
+#pragma unroll
+    for (int blk = 0; blk < AF_BLOCKS; ++blk) {
+        const int kb = af_kb(blk), nt = af_nt(blk);
+        if (blk + AHEAD < AF_BLOCKS) af[blk + AHEAD] = *reinterpret_cast<const u32x4*>(&sm.AF[blk + AHEAD][lane][0]);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            out[nt][j] = mfma_f16(zl[j][kb], af[blk], out[nt][j]);
+            out[nt][j] = mfma_f16(zh[j][kb], af[blk], out[nt][j]);
+        }
+        // tile nt - 1 was finished by the previous block(s): its epilogue goes out under this tile's MFMAs
+        if (nt > 0 && (blk + 1 == AF_BLOCKS || af_nt(blk + 1) != nt)) epilogue(nt - 1);
     }
+    epilogue(5);
     if (LAST) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int col0 = 16 * JT * wave + 4 * (ln >> 4);
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             f32x4 t;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = row16_sum(sum[j][e]) * (1.0f / 81.0f);
-            if (c == 0) *reinterpret_cast<f32x4*>(pooled_out + col0 + 16 * j) = t;
+            for (int e = 0; e < 4; ++e) t[e] = row16_sum(sum[j][e]) * (float)(1.0 / (81.0 * CQ));
+            // (buffer store off an SGPR descriptor + scalar row offset: no 64-bit address registers alive across the board loop)
+            if (c == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), pooled_rs, (col0 + 16 * j) * 4, pooled_soff, 0);
         }
     }
 }
@@ -791,7 +853,8 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
                                                                                         const uint8_t* __restrict__ active, int phase_delay) {
     constexpr int N = 9, V = 81, S = 8;
     constexpr int NWV = 8 / JT;
-    __shared__ TrunkSmemM sm;
+    constexpr int NSLOT = NWV == 4 ? 3 : 2;
+    __shared__ TrunkSmemM<NWV> sm;
     // The two workgroups resident on a CU run identical phase sequences; a start offset for the second-resident ones
     // (phase_delay x 64 cycles) keeps one on the matrix pipe while the other does vector work.
     for (int i = 0; i < (int)(blockIdx.x >> 8) * phase_delay; ++i) __builtin_amdgcn_s_sleep(1);   // 2nd / 3rd resident: 1x / 2x
@@ -804,22 +867,25 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     // A board's record lives in two VGPRs of EVERY wave (each wave fetches it itself: 24-72 bytes), one board ahead:
     //   fmt 0 (state72): rec0 = wall byte of slot `lane`, rec1 = header dword;  fmt 1 (QState): rec0 = dword `lane` (< 5)
     uint32_t rec0 = 0, rec1 = 0;
+    // buffer loads off one SGPR descriptor + a scalar record offset: no 64-bit address registers to keep alive across the loop
+    const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(states), 0, B * (fmt == 0 ? 72 : 24), 0x00020000);
     auto fetch_record = [&](int bb, uint32_t& r0, uint32_t& r1) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));          // offsets are recomputed per fetch, not kept (spilled) across the board loop
         if (fmt == 0) {
-            const uint8_t* r = reinterpret_cast<const uint8_t*>(states) + (size_t)bb * 72;
-            r0 = r[4 + lane];
-            r1 = *reinterpret_cast<const uint32_t*>(r);
+            r0 = __builtin_amdgcn_raw_buffer_load_b8(rst, 4 + ln, bb * 72, 0);
+            r1 = __builtin_amdgcn_raw_buffer_load_b32(rst, 0, bb * 72, 0);
         } else {
-            r0 = reinterpret_cast<const uint32_t*>(states)[(size_t)bb * 6 + (lane < 5 ? lane : 4)];
+            r0 = __builtin_amdgcn_raw_buffer_load_b32(rst, (ln < 5 ? ln : 4) * 4, bb * 24, 0);
         }
     };
     if (b < B) fetch_record(b, rec0, rec1);
     // once per workgroup: the padding rows no board ever writes.  No barrier here: their first reader sits behind the
     // first board's setup barrier.
-    if (tid < 15 * 4) (&sm.X0[81][0])[tid] = 0u;
-    if (tid < 15) sm.dinv[81 + tid] = 0.f;
+    if (tid < 15) { sm.sqd[81 + tid] = 0.f; sm.dnv[81 + tid] = 0.f; }
     u32x4 Bf[2][JT][4];
     const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pooled, 0, B * (HID * 4), 0x00020000);
 
     AQG_STAMP_DECL
     while (b < B) {
@@ -839,12 +905,23 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
                 vw = __ballot((rec0 & 2u) != 0);
                 hd = __builtin_amdgcn_readfirstlane(rec1);
             } else {
-                hw = (uint64_t)__builtin_amdgcn_readlane(rec0, 0) | ((uint64_t)__builtin_amdgcn_readlane(rec0, 1) << 32);
-                vw = (uint64_t)__builtin_amdgcn_readlane(rec0, 2) | ((uint64_t)__builtin_amdgcn_readlane(rec0, 3) << 32);
-                hd = __builtin_amdgcn_readlane(rec0, 4);
+                // (readlane returns a SIGNED int: without the uint32_t cast a wall in slot 31 sign-extends into slots 32..63 --
+                //  a round-1 bug that only the in-engine evaluation path could hit; tests/test_gpu_parity.py pins it now)
+                hw = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(rec0, 0) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(rec0, 1) << 32);
+                vw = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(rec0, 2) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(rec0, 3) << 32);
+                hd = (uint32_t)__builtin_amdgcn_readlane(rec0, 4);
             }
             const Open op = make_open<N>(hw, vw);
-            auto open_word = [&](const BB& m, int w) -> uint32_t { return w == 0 ? (uint32_t)m.lo : w == 1 ? (uint32_t)(m.lo >> 32) : (uint32_t)m.hi; };
+            // the four open-edge boards as 3 x 32-bit words each (word w = nodes 32 w .. 32 w + 31), selected arithmetically
+            // (scalars, not an array: an indexed local array would live in scratch memory)
+            const uint32_t u0 = (uint32_t)op.U.lo, u1 = (uint32_t)(op.U.lo >> 32), u2 = (uint32_t)op.U.hi;
+            const uint32_t d0w = (uint32_t)op.D.lo, d1w = (uint32_t)(op.D.lo >> 32), d2w = (uint32_t)op.D.hi;
+            const uint32_t l0 = (uint32_t)op.L.lo, l1 = (uint32_t)(op.L.lo >> 32), l2 = (uint32_t)op.L.hi;
+            const uint32_t r0w = (uint32_t)op.R.lo, r1w = (uint32_t)(op.R.lo >> 32), r2w = (uint32_t)op.R.hi;
+            auto sel3 = [](uint32_t a0, uint32_t a1, uint32_t a2, int w) -> uint32_t { const uint32_t a = w == 0 ? a0 : a1; return w == 2 ? a2 : a; };
+            auto open_word = [&](int dir, int w) -> uint32_t {
+                return dir == 0 ? sel3(u0, u1, u2, w) : dir == 1 ? sel3(d0w, d1w, d2w, w) : dir == 2 ? sel3(l0, l1, l2, w) : sel3(r0w, r1w, r2w, w);
+            };
             if (tid < V) {
                 int t = tid;
                 asm volatile("" : "+v"(t));   // opaque per iteration: nothing per-tile is hoisted out of the board loop
@@ -859,39 +936,65 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
                 xr[3] = 0u;
                 *reinterpret_cast<u32x4*>(&sm.X0[t][0]) = xr;
                 const int w = t >> 5, sft = t & 31;
-                const uint32_t deg = 1u + ((open_word(op.U, w) >> sft) & 1u) + ((open_word(op.D, w) >> sft) & 1u) +
-                                     ((open_word(op.L, w) >> sft) & 1u) + ((open_word(op.R, w) >> sft) & 1u);
-                sm.dinv[t] = dinv_of((int)deg);
+                const uint32_t deg = 1u + ((open_word(0, w) >> sft) & 1u) + ((open_word(1, w) >> sft) & 1u) +
+                                     ((open_word(2, w) >> sft) & 1u) + ((open_word(3, w) >> sft) & 1u);
+                sm.dnv[t] = dinv_of((int)deg);
+                sm.sqd[t] = deg == 1u ? 1.0f : deg == 2u ? 1.41421356237309505f : deg == 3u ? 1.73205080756887729f : deg == 4u ? 2.0f : 2.23606797749978970f;
             }
-            // ten adjacency blocks over the waves, the two waves that also write X0 / dinv getting the fewest:
+            // ten adjacency blocks over the waves, the two waves that also write X0 / sqd / dnv getting the fewest:
             //   8 waves: w0 {8}  w1 {9}  w2 {0,6}  w3 {1,7}  w4..7 {2..5}      4 waves: w0 {0,4}  w1 {1,5}  w2 {2,6,8}  w3 {3,7,9}
+            auto slot_block = [&](int it) -> int {                           // wave-uniform
+                if (NWV == 8) return it == 0 ? (wave >= 2 ? wave - 2 : wave + 8) : ((wave == 2 || wave == 3) ? wave + 4 : AF_BLOCKS);
+                return it < 2 ? wave + 4 * it : (wave >= 2 ? wave + 6 : AF_BLOCKS);
+            };
+            // step 1: the fp16 values CQ / deg(k) of the 32 source nodes of each block's k range, through this wave's own LDS
+            //         scratch (lane l < 32 = node 32 kb + l; the word of the open-edge boards is wave-uniform)
 #pragma unroll
-            for (int it = 0; it < (NWV == 8 ? 2 : 3); ++it) {
-                int blk;                                                      // wave-uniform
-                if (NWV == 8) blk = it == 0 ? (wave >= 2 ? wave - 2 : wave + 8) : ((wave == 2 || wave == 3) ? wave + 4 : AF_BLOCKS);
-                else blk = it < 2 ? wave + 4 * it : (wave >= 2 ? wave + 6 : AF_BLOCKS);
+            for (int it = 0; it < NSLOT; ++it) {
+                const int blk = slot_block(it);
+                if (blk < AF_BLOCKS && lane < 32) {
+                    const int kb = (AF_KB_PACK >> (2 * blk)) & 3;
+                    int l = lane;
+                    asm volatile("" : "+v"(l));
+                    const uint32_t deg = 1u + ((open_word(0, kb) >> l) & 1u) + ((open_word(1, kb) >> l) & 1u) +
+                                         ((open_word(2, kb) >> l) & 1u) + ((open_word(3, kb) >> l) & 1u);
+                    // fp16 of CQ / deg = 0.9375, 0.46875, 0.3125, 0.234375, 0.1875 (all exact)
+                    const uint32_t val = deg == 1u ? 0x3B80u : deg == 2u ? 0x3780u : deg == 3u ? 0x3500u : deg == 4u ? 0x3380u : 0x3200u;
+                    sm.degv[wave][it][l] = (unsigned short)((32 * kb + l < V) ? val : 0u);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // step 2: the fragments.  k-slot e of lane (c, q) is node 32 kb + 16 (e >> 2) + 4 q + (e & 3); entry = CQ / deg(k) where
+            //         node n = 16 nt + c has k in its closed neighbourhood, else 0
+#pragma unroll
+            for (int it = 0; it < NSLOT; ++it) {
+                const int blk = slot_block(it);
                 if (blk < AF_BLOCKS) {
                     const int kb = (AF_KB_PACK >> (2 * blk)) & 3, nt = (AF_NT_PACK >> (3 * blk)) & 7;
-                    int n = 16 * nt + c;
-                    asm volatile("" : "+v"(n));
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));      // opaque per board: no per-slot lane constant is kept alive (spilled) across the loop
+                    const int n = 16 * nt + (ln & 15), q = ln >> 4;
                     u32x4 fr = (u32x4){0u, 0u, 0u, 0u};
                     if (n < V) {
                         const int w = nt >> 1, sft = n & 31;                 // n >> 5 == nt >> 1: the word is wave-uniform
                         // window of row n of (A + I) around the diagonal: bit (k - n + 9), k = n-9 (U), n-1 (L), n, n+1 (R), n+9 (D)
-                        const uint32_t win = (1u << 9) | ((open_word(op.U, w) >> sft) & 1u) | (((open_word(op.L, w) >> sft) & 1u) << 8) |
-                                             (((open_word(op.R, w) >> sft) & 1u) << 10) | (((open_word(op.D, w) >> sft) & 1u) << 18);
+                        const uint32_t win = (1u << 9) | ((open_word(0, w) >> sft) & 1u) | (((open_word(2, w) >> sft) & 1u) << 8) |
+                                             (((open_word(3, w) >> sft) & 1u) << 10) | (((open_word(1, w) >> sft) & 1u) << 18);
                         const int d0 = 32 * kb + 4 * q - n + 9;              // window bit of k-slot e = 0; e = 4 sits 16 higher
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
+                            const u32x2 dv = *reinterpret_cast<const u32x2*>(&sm.degv[wave][it][16 * h + 4 * q]);   // nodes 32 kb + 16 h + 4 q + 0..3
                             const int d = d0 + 16 * h;
                             uint32_t nib = (d >= 0) ? (win >> min(d, 31)) : (win << min(-d, 4));
                             nib &= 0xFu;
                             const uint32_t t2 = nib | (nib << 15);           // b0 -> bit 0, b1 -> bit 16, b2 -> bit 2, b3 -> bit 18
-                            fr[2 * h] = (t2 & 0x00010001u) * 0x3C00u;        // fp16 1.0 = 0x3C00 in each selected half
-                            fr[2 * h + 1] = (t2 & 0x00040004u) * 0x0F00u;
+                            fr[2 * h] = ((t2 & 0x00010001u) * 0xFFFFu) & dv[0];          // 0xFFFF in each selected half
+                            fr[2 * h + 1] = (((t2 >> 2) & 0x00010001u) * 0xFFFFu) & dv[1];
                         }
                     }
-                    *reinterpret_cast<u32x4*>(&sm.AF[blk][lane][0]) = fr;
+                    *reinterpret_cast<u32x4*>(&sm.AF[blk][ln][0]) = fr;
                 }
             }
         }
@@ -899,54 +1002,65 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         while (bn < B && active && !active[bn]) bn += gridDim.x;
         __syncthreads();
         AQG_STAMP_AT(0)
-        f32x4 acc[6][JT], out[6][JT];
-        // ---- layer 1: Z = X0 W1 (one MFMA per tile), aggregation, planes
+        // byte offset of this lane's rows in a bias table, (deg - 1) * 512 + 16 q with deg = round(sqd^2) (first row for the
+        // padding nodes), two node tiles per register
+        int toff[3];
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) {
+            const float sq = sm.sqd[16 * nt + c];
+            const int o = max((int)(sq * sq + 0.5f) - 1, 0) * (HID * 4) + 16 * q;
+            toff[nt >> 1] = (nt & 1) ? (toff[nt >> 1] | (o << 16)) : o;
+        }
+        f32x4 out[6][JT];
+        u32x4 zh[JT][3], zl[JT][3];
+        // ---- layer 1: U = sqrt(deg) (.) (X0 W1) (one MFMA per tile), aggregation, planes
+        request_bias<JT>(out, rs, 0, toff, wave);
 #pragma unroll
         for (int m = 0; m < 6; ++m) {
-            u32x4 xf = *reinterpret_cast<const u32x4*>(&sm.X0[16 * m + c][0]);
-            if (q >= 2) xf = (u32x4){0u, 0u, 0u, 0u};
+            // (lanes q >= 2 meet zero rows of the weight fragment: their copy of the features contributes nothing)
+            const u32x4 xf = *reinterpret_cast<const u32x4*>(&sm.X0[m < 5 ? 16 * m + c : 80][0]);
+            const f32x4 sq4 = *reinterpret_cast<const f32x4*>(&sm.sqd[16 * m + 4 * q]);   // 0 beyond node 80: clears tile 5's duplicate rows
 #pragma unroll
-            for (int j = 0; j < JT; ++j) acc[m][j] = mfma_f16(xf, w1f[j], (f32x4){0.f, 0.f, 0.f, 0.f});
+            for (int j = 0; j < JT; ++j) {
+                const f32x4 u = mfma_f16(xf, w1f[j], (f32x4){0.f, 0.f, 0.f, 0.f}) * sq4;
+#pragma unroll
+                for (int piece = 0; piece < 3; ++piece) split_tile_piece(u, m, piece, zh[j], zl[j]);
+            }
         }
         AQG_STAMP_AT(8)
-        f32x4 bias4[JT];
-        load_bias<JT>(bias4, rs, PackedLayout::B1, wave, lane);
-        adj_matmul<JT>(sm, acc, lane, out);
         __builtin_amdgcn_sched_barrier(0);
-        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights: land under the plane stores + barrier
+        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights: land under the aggregation + barrier
         __builtin_amdgcn_sched_barrier(0);
+        aggregate_store<JT, false>(sm, zh, zl, out, wave, lane, prs, 0);     // (nobody reads the planes now: stores need no barrier)
         AQG_STAMP_AT(9)
-        adj_store<JT, false>(sm, out, bias4, wave, lane, nullptr);
         AQG_STAMP_AT(10)
         __syncthreads();
         AQG_STAMP_AT(1)
         // ---- layer 2
-        stripe_matmul_mm<JT>(sm, Bf, lane, acc);
+        request_bias<JT>(out, rs, 1, toff, wave);
+        linear_split<JT>(sm, Bf, lane, zh, zl);
         AQG_STAMP_AT(2)
         AQG_STAMP_AT(11)
-        load_bias<JT>(bias4, rs, PackedLayout::B2, wave, lane);
-        adj_matmul<JT>(sm, acc, lane, out);
         __builtin_amdgcn_sched_barrier(0);
-        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH3, wave, lane);             // lands under the barrier + plane stores (its 32
-        uint32_t nrec0 = 0, nrec1 = 0;                                      // registers are needed by the adjacency fragments
-        if (bn < B) fetch_record(bn, nrec0, nrec1);                         // before); the next board's record rides behind it
+        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH3, wave, lane);             // lands under the barrier + aggregation
+        uint32_t nrec0 = 0, nrec1 = 0;
+        if (bn < B) fetch_record(bn, nrec0, nrec1);                         // the next board's record rides behind it
         __builtin_amdgcn_sched_barrier(0);
         AQG_STAMP_AT(12)
         __syncthreads();                                                    // every wave is done reading the planes
         AQG_STAMP_AT(13)
-        adj_store<JT, false>(sm, out, bias4, wave, lane, nullptr);
+        aggregate_store<JT, false>(sm, zh, zl, out, wave, lane, prs, 0);
         AQG_STAMP_AT(14)
         __syncthreads();
         AQG_STAMP_AT(3)
         // ---- layer 3 + mean pool
-        stripe_matmul_mm<JT>(sm, Bf, lane, acc);
+        request_bias<JT>(out, rs, 2, toff, wave);
+        linear_split<JT>(sm, Bf, lane, zh, zl);
         AQG_STAMP_AT(4)
-        load_bias<JT>(bias4, rs, PackedLayout::B3, wave, lane);
-        adj_matmul<JT>(sm, acc, lane, out);
         AQG_STAMP_AT(15)
-        adj_store<JT, true>(sm, out, bias4, wave, lane, pooled + (size_t)b * HID);
+        aggregate_store<JT, true>(sm, zh, zl, out, wave, lane, prs, b * (HID * 4));
         rec0 = nrec0; rec1 = nrec1;
-        if (bn < B) __syncthreads();                                        // AF / X0 / dinv / planes are free for the next board
+        if (bn < B) __syncthreads();                                        // AF / X0 / sqd / dnv / planes are free for the next board
                                                                             // (bn is workgroup-uniform; the last board needs no barrier)
         AQG_STAMP_AT(5)
 #ifdef AQG_STAMP
@@ -963,6 +1077,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------
 // heads: 16 boards per workgroup
 // ---------------------------------------------------------------------------------------------
@@ -1275,9 +1390,8 @@ __global__ __launch_bounds__(256, 2) void gcn_heads_mm_kernel(const float* __res
 
 // Trunk variants (aqg_set_option("trunk_variant", v)):
 //   0 exact f32-input MFMA + VALU gather, weights resident, 1 workgroup/CU      1 the same, 2 workgroups/CU
-//   3 all-MFMA fp16 split trunk, form chosen per launch  [default]: 8 waves per board x 2 workgroups/CU below 768 boards,
-//     4 waves per board x 3 workgroups/CU from 768 boards
-//   4 force 4 waves per board x 3/CU      5 force 4 waves per board x 2/CU      6 force 8 waves per board x 2/CU
+//   3 all-MFMA fp16 split trunk [default] = 6: 8 waves per board x 2 workgroups/CU
+//   5 (and 4, kept as an alias of the retired three-workgroups-per-CU form) 4 waves per board x 2 workgroups/CU
 // An earlier split-precision kernel kept the VALU gather of variants 0/1 on a 16-bit plane image (bf16 x6 / x3 and
 // fp16 x3 forms).  It was removed: its gather read plane bytes no wave had written for the current board (harmless
 // with benign leftovers, wrong once the LDS held NaN patterns -- tools/cold_launch_check.py poisons the LDS before
@@ -1314,7 +1428,7 @@ static long long g_prof_boards = 0;
 static hipEvent_t prof_event() {
     if (g_prof_used == g_prof_events.size()) {
         hipEvent_t e;
-        hipEventCreate(&e);
+        (void)hipEventCreate(&e);
         g_prof_events.push_back(e);
     }
     return g_prof_events[g_prof_used++];
@@ -1341,39 +1455,37 @@ int profile_collect(double* total_ms, long long* launches, long long* boards, in
 
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
-                              hipStream_t st) {
+                              int flags, hipStream_t st) {
     if (N != 9) return fail("fused board trunk is built for 9x9; use aqg_gcn_forward_graph for other sizes");
     if (B <= 0) return 0;
     if (!pooled) return fail("pooled workspace is required");
     if (N * N + 2 * (N - 1) * (N - 1) > 248) return fail("policy size exceeds 248");
     const int A = N * N + 2 * (N - 1) * (N - 1);
     // persistent grid: 256 CUs x resident workgroups per CU, grid-stride over boards
-    if (g_profile_trunk) { hipEventRecord(prof_event(), st); g_prof_boards += B; }
-    if (g_trunk_variant == 0) {
+    const int variant = (flags & 1) ? (g_trunk_variant == 0 ? 0 : 1) : g_trunk_variant;   // AQG_GNN_EXACT_F32
+    if (g_profile_trunk) { (void)hipEventRecord(prof_event(), st); g_prof_boards += B; }
+    if (variant == 0) {
         int grid = B < 256 ? B : 256;
         hipLaunchKernelGGL((gcn_trunk_boards_kernel<true, 1>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
-    } else if (g_trunk_variant == 1) {
+    } else if (variant == 1) {
         int grid = B < 512 ? B : 512;
         hipLaunchKernelGGL((gcn_trunk_boards_kernel<false, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
-    } else if (g_trunk_variant == 5) {
+    } else if (variant == 4 || variant == 5) {
+        // two 4-wave workgroups per CU (a wave owns 32 feature columns): half the LDS operand traffic of the 8-wave form
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
         hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0);
-    } else if (g_trunk_variant == 4 || (g_trunk_variant == 3 && B >= 768)) {
-        // three 4-wave workgroups per CU: more boards in flight per CU; wins from ~768 boards per launch (tools/phase_scan.py)
-        int grid = B < 768 ? B : 768;
-        if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 3>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, B >= g_trunk_delay_min_boards ? g_trunk_phase_delay / 2 : 0);
     } else {
-        // two 8-wave workgroups per CU: shortest latency per board, best when a launch has at most ~2 boards per CU
+        // two 8-wave workgroups per CU (a wave owns 16 feature columns): shortest latency per board AND, with four waves per
+        // SIMD to hide each other's vector work, the highest throughput at every launch size (tools/trunk_scan.py)
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
         hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0);
     }
-    if (g_profile_trunk) hipEventRecord(prof_event(), st);
+    if (g_profile_trunk) (void)hipEventRecord(prof_event(), st);
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;
     if (!logits && !policy && !value_pre && !value) return 0;   // trunk only (bench: time the dominant kernel alone)
-    if (g_trunk_variant >= 3 && A <= 14 * 16) {
+    if (variant >= 3 && A <= 14 * 16) {
         hipLaunchKernelGGL(gcn_heads_mm_kernel, dim3((B + 15) / 16), dim3(256), 0, st, (const float*)pooled, B, A, packed,
                            logits, policy, value_pre, value, active);
         return check_launch("gcn_heads_mm_kernel");
@@ -1535,8 +1647,8 @@ size_t boards_any_workspace_floats(int N, int B) { return (size_t)B * N * N * 27
 
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
-                                  float* value, const uint8_t* active, hipStream_t st) {
-    if (N == 9) return launch_gcn_forward_boards(N, states, fmt, B, packed, pooled, logits, policy, value_pre, value, active, st);
+                                  float* value, const uint8_t* active, int flags, hipStream_t st) {
+    if (N == 9) return launch_gcn_forward_boards(N, states, fmt, B, packed, pooled, logits, policy, value_pre, value, active, flags, st);
     if (!(N == 3 || N == 5 || N == 7)) return fail("board_size must be 3, 5, 7 or 9");
     if (B <= 0) return 0;
     if (!pooled) return fail("pooled workspace is required");

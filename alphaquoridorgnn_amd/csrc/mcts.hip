@@ -29,12 +29,12 @@ int launch_legal_actions(int N, const void* states, int fmt, int B, uint8_t* mas
                          const uint8_t* active, hipStream_t st);
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
-                              hipStream_t st);
+                              int flags, hipStream_t st);
 size_t boards_any_workspace_floats(int N, int B);
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
-                                  float* value, const uint8_t* active, hipStream_t st);
-extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_profile_trunk;
+                                  float* value, const uint8_t* active, int flags, hipStream_t st);
+extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, g_profile_trunk;
 int g_use_graph = 1;       // aqg_set_option("use_graph", 0) forces plain launches
 
 __device__ __forceinline__ int wave_sum_i(int v) {
@@ -83,8 +83,18 @@ __device__ __forceinline__ void backup_path(NodeRec* __restrict__ nodes, const i
 __global__ void engine_reset_kernel(aqg_engine e) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g == 0) {
-        e.counters[0] = e.num_games;
-        for (int i = 1; i < 8; ++i) e.counters[i] = 0;
+        e.counters[0] = e.num_games;          // active slots
+        e.counters[1] = 0;                    // finished games
+        e.counters[2] = 0;                    // dead-end aborts
+        e.counters[3] = e.num_games;          // next game index to hand out (slot refill)
+        for (int i = 4; i < 8; ++i) e.counters[i] = 0;
+    }
+    if (g < e.quota) {                        // per-game records (quota >= num_games)
+        e.game_plies[g] = 0;
+        e.game_result[g] = 0;
+        e.game_done[g] = 0;
+        e.game_slot[g] = g < e.num_games ? g : -1;
+        e.game_first_move[g] = 0;
     }
     if (g >= e.num_games) return;
     const int N = e.board_size;
@@ -95,8 +105,7 @@ __global__ void engine_reset_kernel(aqg_engine e) {
     s.plies = 0; s.pad = 0;
     store_state(e.root_state, g, s);
     e.game_active[g] = 1;
-    e.game_plies[g] = 0;
-    e.game_result[g] = 0;
+    e.slot_game[g] = g;
     e.node_count[g] = 0;
     e.leaf_flag[g] = 0;
     e.stat_leaf_evals[g] = 0;
@@ -108,6 +117,7 @@ __global__ void engine_set_roots_kernel(aqg_engine e, const uint8_t* __restrict_
     if (g >= e.num_games) return;
     store_state(e.root_state, g, unpack72(roots72 + (size_t)g * STATE72));
     e.game_active[g] = 1;
+    e.slot_game[g] = g;
     e.game_plies[g] = 0;
 }
 
@@ -121,10 +131,11 @@ __global__ void engine_begin_move_kernel(aqg_engine e) {
     root.w = 0.0; root.p = 0.f; root.n = 0; root.kids = 0; root.action = 0xFF; root.pad[0] = 0; root.pad[1] = 0;
     game_nodes(e, g)[0] = root;
     e.node_count[g] = 1;
-    const int ply = e.game_plies[g];
+    const int k = e.slot_game[g];                  // the game this slot is playing
+    const int ply = e.game_plies[k];
     if (e.hist_visits && ply < e.max_plies) {      // clear this ply's dense visit row (filled by finish_move)
         const int A = e.board_size * e.board_size + 2 * (e.board_size - 1) * (e.board_size - 1);
-        uint16_t* hv = e.hist_visits + ((size_t)g * e.max_plies + ply) * A;
+        uint16_t* hv = e.hist_visits + ((size_t)k * e.max_plies + ply) * A;
         for (int a = 0; a < A; ++a) hv[a] = 0;
     }
 }
@@ -346,12 +357,295 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same step with the dependent memory rounds cut to the minimum (default; aqg_set_option("step_variant", 0) = the
+// two functions above behind one workgroup-scope fence).  The step is a latency chain: above, every phase waits for
+// its own loads -- scalars, legal list, policy gather, path, read-modify-write of the path nodes, root children, one
+// round per tree level -- about ten dependent round trips to L2/HBM per simulation.  Here:
+//   round 1   everything whose address follows from (game, lane) alone is requested at once: scalars, root state,
+//             legal list, old path, the whole policy row, the root record AND the root's children (node 1 ...: the root
+//             is expanded first in every move, so its children always start at node 1);
+//   no store -> load dependency inside the kernel: the previous simulation's backup and expansion are APPLIED IN
+//             REGISTERS to whatever the descent loads (a child on the old path gets w += +-v, n += 1 -- the same
+//             float64 addition the store performs; the old leaf's children are the records just built), and written to
+//             memory behind the descent.  Every load therefore sees the state the previous launch left, whatever the
+//             timing, and the descent's only dependent rounds are the child blocks of levels >= 2;
+//   the policy gather at the legal actions goes through 1 KB of LDS instead of a second global round.
+// Identical arithmetic, identical visit order: bit-exact with the reference traces like the variant above.  Paths
+// deeper than `fast_depth` (61; never seen) fall back to that variant mid-flight: pending updates are flushed, fenced,
+// and the descent continues on memory (the tests run the goldens with fast_depth 1 and 2 to exercise every hand-over).
+// ------------------------------------------------------------------------------------------------
+int g_step_variant = 1;
+int g_step_fast_depth = 61;
+
+template <int N>
+__device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int lane, int do_expand, int do_select, int fast_depth,
+                                               float* __restrict__ polbuf /* this wave's 256 floats of LDS */) {
+    constexpr int A = Geo<N>::A;
+    NodeRec* __restrict__ nodes = game_nodes(e, g);
+    int* path = e.path + (size_t)g * (e.sims + 2);
+    const uint8_t* ord = e.legal_order + (size_t)g * MAX_LEGAL;
+    const float* pol = e.policy + (size_t)g * A;
+    // ---------------- round 1
+    const int active = e.game_active[g];
+    QState s = load_state(e.root_state, 1, g);
+    int flag = 0, depth_old = 0, cnt_new = 0, first_new = 0;
+    float value = 0.f;
+    uint8_t oa[3] = {0, 0, 0};
+    int pnode = 0;
+    float polr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (do_expand) {
+        flag = e.leaf_flag[g]; depth_old = e.path_len[g]; cnt_new = e.legal_count[g]; first_new = e.node_count[g]; value = e.value[g];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { const int i = lane + 64 * r; oa[r] = (i < MAX_LEGAL) ? ord[i] : (uint8_t)0; }
+        pnode = (lane < e.sims + 2) ? path[lane] : 0;
+        if (e.prior_mode == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int a = lane + 64 * r; polr[r] = (a < A) ? pol[a] : 0.f; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { const int i = lane + 64 * r; polr[r] = (i < MAX_LEGAL && i < A) ? pol[i] : 0.f; }
+        }
+    }
+    const NodeRec rootrec = nodes[0];
+    NodeRec rc[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) rc[r] = nodes[min(1 + lane + 64 * r, e.node_cap - 1)];
+    if (!do_expand) flag = 0;
+    if (flag != 1 && !do_select) return;
+
+    // ---------------- previous simulation: priors, new children, backup deltas (registers; stores issued, nothing re-read)
+    const bool expanded = flag == 1 && cnt_new > 0 && first_new + cnt_new <= e.node_cap;
+    const int leaf_old = flag == 1 ? (depth_old < 64 ? __shfl(pnode, depth_old & 63) : path[depth_old]) : -1;
+    float pl[3] = {0.f, 0.f, 0.f};
+    if (flag == 1) {
+        if (e.prior_mode == 0) {     // P0: gather at the legal actions, divide by the sum unless 0 (pv_network_cnn.py:129-132)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) polbuf[lane + 64 * r] = polr[r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int i = lane + 64 * r;
+                pl[r] = (i < cnt_new) ? polbuf[oa[r]] : 0.f;
+                sum += pl[r];
+            }
+            sum = wave_sum_f(sum);
+            const float den = (sum != 0.f) ? sum : 1.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) pl[r] = pl[r] / den;
+        } else {                     // fake evaluator: legal-ordered normalised priors
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { const int i = lane + 64 * r; pl[r] = (i < cnt_new) ? polr[r] : 0.f; }
+        }
+        if (expanded) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int i = lane + 64 * r;
+                if (i < cnt_new) {
+                    NodeRec c;
+                    c.w = 0.0; c.p = pl[r]; c.n = 0; c.kids = 0; c.action = oa[r]; c.pad[0] = 0; c.pad[1] = 0;
+                    nodes[first_new + i] = c;
+                }
+            }
+            if (lane == 0) {
+                nodes[leaf_old].kids = (uint32_t)first_new | ((uint32_t)cnt_new << 24);
+                e.node_count[g] = first_new + cnt_new;
+            }
+        }
+        if (lane == 0) e.stat_leaf_evals[g] += 1;
+    }
+    const uint32_t kids_new = expanded ? ((uint32_t)first_new | ((uint32_t)cnt_new << 24)) : 0u;
+    const double v_old = (double)value;                              // value.item() -> python float
+    // lane d <= depth_old holds the old path node at depth d: its record after the backup (pv_mcts.py:60-66), store pending
+    double bw = 0.0; int bn = 0;
+    const bool fast_old = flag == 1 && depth_old <= fast_depth && depth_old < 63;
+    if (flag == 1 && fast_old) {
+        if (lane <= depth_old) {
+            const NodeRec& r = nodes[pnode];
+            bw = r.w + (((depth_old - lane) & 1) ? -v_old : v_old);
+            bn = r.n + 1;
+        }
+    }
+    bool pending = fast_old;          // the old path's updated (w, n) are in registers, not in memory
+    auto flush_old = [&]() {
+        if (pending && lane <= depth_old) { NodeRec& r = nodes[pnode]; r.w = bw; r.n = bn; }
+        pending = false;
+    };
+    if (flag == 1 && !fast_old) {     // deep old path: plain read-modify-write through memory, then everything below reads memory
+        if (lane <= depth_old && lane < 64) {
+            NodeRec& r = nodes[pnode];
+            r.w += ((depth_old - lane) & 1) ? -v_old : v_old;
+            r.n += 1;
+        }
+        for (int d = lane + 64; d <= depth_old; d += 64) {
+            NodeRec& r = nodes[path[d]];
+            r.w += ((depth_old - d) & 1) ? -v_old : v_old;
+            r.n += 1;
+        }
+    }
+    if (!do_select) { flush_old(); return; }
+    if (!active) { flush_old(); if (lane == 0) e.leaf_flag[g] = 0; return; }
+    if (lane == 0) e.leaf_flag[g] = 0;
+
+    // ---------------- descent (pv_mcts.py:33-66 via :69-78)
+    bool regs = true;                 // round-1 / register copies are current (false after a fall-back to memory)
+    if (flag == 1 && !fast_old) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        regs = false;
+    }
+    int node = 0, depth = 0;
+    int mynode = 0;                   // lane d: new path node at depth d ...
+    double nw = 0.0; int nn = 0;      // ... and its current (w, n), pending updates included
+    if (lane == 0) {
+        path[0] = 0;
+        if (regs) { nw = (flag == 1 && fast_old) ? bw : rootrec.w; nn = (flag == 1 && fast_old) ? bn : rootrec.n; }
+    }
+    bool onpath = flag == 1 && fast_old;     // the current node IS the old path's node at this depth
+    int terminal = 0;
+    double tvalue = 0.0;
+    uint32_t kids = regs ? ((onpath && depth_old == 0) ? kids_new : rootrec.kids) : nodes[0].kids;
+    // children of the current node, fetched one level ahead of their use: the root's come from round 1, the old leaf's are
+    // the records just built, everything else is one dependent load round per level
+    NodeRec rec[3];
+    auto fetch_children = [&](uint32_t k, bool built_now) {
+        const int cnt = (int)(k >> 24), first = (int)(k & 0xFFFFFF);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = lane + 64 * r;
+            if (built_now) { rec[r].w = 0.0; rec[r].p = pl[r]; rec[r].n = 0; rec[r].kids = 0; rec[r].action = oa[r]; }
+            else if (i < cnt) rec[r] = nodes[first + i];
+            else { rec[r].w = 0.0; rec[r].p = 0.f; rec[r].n = 0; rec[r].kids = 0; rec[r].action = 0; }
+        }
+    };
+    if (regs && onpath && depth_old == 0) fetch_children(kids, true);
+    else if (regs) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) rec[r] = rc[r];
+    } else fetch_children(kids, false);
+    for (;;) {
+        const bool lose = is_lose<N>(s), draw = is_draw(s, e.plies_for_draw);
+        if (lose || draw) { tvalue = lose ? -1.0 : 0.0; terminal = 1; break; }      // pv_mcts.py:35-42
+        const int cnt = (int)(kids >> 24), first = (int)(kids & 0xFFFFFF);
+        if (cnt == 0) break;                                                         // pv_mcts.py:45 unexpanded leaf
+        // the old path's child of this node: backup delta and (if it is the old leaf) its new child range, in registers
+        const bool patch = regs && onpath && depth < depth_old;
+        const int pchild = patch ? __shfl(pnode, (depth + 1) & 63) : -1;
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = lane + 64 * r;
+            if (i < cnt) {
+                if (first + i == pchild) {
+                    rec[r].w += ((depth_old - (depth + 1)) & 1) ? -v_old : v_old;
+                    rec[r].n += 1;
+                    if (depth + 1 == depth_old) rec[r].kids = kids_new;
+                }
+                t += rec[r].n;
+            }
+        }
+        t = wave_sum_i(t);
+        const float st = (float)sqrt((double)t);              // f32(math.sqrt(t))
+        float best = -INFINITY; int besti = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = lane + 64 * r;
+            if (i < cnt) {
+                const float u = ((e.c_puct * rec[r].p) * st) / (float)(1 + rec[r].n);
+                const float q = rec[r].n ? (float)(-rec[r].w / (double)rec[r].n) : 0.0f;
+                const float sc = q + u;
+                if (sc > best) { best = sc; besti = i; }       // strict > keeps the lowest index within a lane
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {               // (max score, min index) across the wave
+            const float ob = __shfl_xor(best, off);
+            const int oi = __shfl_xor(besti, off);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if (besti == 0x7fffffff) besti = 0;                    // all-NaN guard (np.argmax would return 0)
+        const int slot = besti >> 6, src = besti & 63;
+        const uint32_t k_sel = slot == 0 ? rec[0].kids : (slot == 1 ? rec[1].kids : rec[2].kids);
+        const uint32_t a_sel = slot == 0 ? rec[0].action : (slot == 1 ? rec[1].action : rec[2].action);
+        const double w_sel = slot == 0 ? rec[0].w : (slot == 1 ? rec[1].w : rec[2].w);
+        const int n_sel = slot == 0 ? rec[0].n : (slot == 1 ? rec[1].n : rec[2].n);
+        kids = (uint32_t)__shfl((int)k_sel, src);
+        const int action = __shfl((int)a_sel, src);
+        // the chosen child's current statistics travel to lane depth + 1 (used only if the path ends on a terminal node)
+        const double cw = __shfl(w_sel, src);
+        const int cn = __shfl(n_sel, src);
+        node = first + besti;
+        onpath = onpath && depth < depth_old && node == pchild;
+        s = next_state<N>(s, action);
+        ++depth;
+        if (lane == 0) path[depth] = node;
+        if (lane == (depth & 63) && depth < 64) { mynode = node; nw = cw; nn = cn; }
+        // next level's children
+        if (regs && depth >= fast_depth) {          // hand over to memory: flush what is pending, fence, go on reading memory
+            flush_old();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            regs = false;
+        }
+        fetch_children(kids, regs && onpath && depth == depth_old);
+    }
+    if (terminal) {
+        // backup of THIS simulation (pv_mcts.py:36-42).  Pending old-path stores go first; the new path's stores carry both
+        // updates for the nodes the two paths share (same wavefront, same address: stores keep their order).
+        if (regs) {
+            flush_old();
+            if (lane <= depth && lane < 64) {
+                NodeRec& r = nodes[mynode];
+                r.w = nw + (((depth - lane) & 1) ? -tvalue : tvalue);
+                r.n = nn + 1;
+            }
+        } else {
+            if (lane <= depth && lane < 64) {
+                NodeRec& r = nodes[mynode];
+                r.w += ((depth - lane) & 1) ? -tvalue : tvalue;
+                r.n += 1;
+            }
+        }
+        if (lane == 0) {
+            e.stat_terminal_sims[g] += 1;
+            for (int d = 64; d <= depth; ++d) {
+                NodeRec& r = nodes[path[d]];
+                r.w += ((depth - d) & 1) ? -tvalue : tvalue;
+                r.n += 1;
+            }
+        }
+    } else {
+        flush_old();
+        const int total = wave_legal_actions<N>(s, lane, nullptr, e.legal_order + (size_t)g * MAX_LEGAL);
+        if (lane == 0) {
+            store_state(e.leaf_state, g, s);
+            e.legal_count[g] = total;
+            e.path_len[g] = depth;
+            e.leaf_flag[g] = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused simulation step, one wavefront per game:
 //   [expand + backup of the PREVIOUS simulation's leaf]  ->  [select the next leaf + its legal actions]
 // Both halves touch only this game's pools, and the wave that wrote the children is the wave that reads them, so
 // a workgroup-scope fence is all the ordering needed.  Per simulation the engine then launches
 // step -> GNN trunk -> GNN heads (3 kernels instead of select / legal / trunk / heads / expand).
 // ------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void engine_step_fast_kernel(aqg_engine e, int do_expand, int do_select, int fast_depth) {
+    __shared__ float polbuf[4][256];
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= e.num_games) return;
+    game_step_fast<N>(e, g, lane, do_expand, do_select, fast_depth, polbuf[threadIdx.x >> 6]);
+}
+
 template <int N>
 __global__ __launch_bounds__(256) void engine_step_kernel(aqg_engine e, int do_expand, int do_select) {
     const int lane = threadIdx.x & 63;
@@ -374,6 +668,13 @@ __global__ __launch_bounds__(256) void engine_step_kernel(aqg_engine e, int do_e
     }
 }
 
+template <int N>
+static void launch_step(const aqg_engine& e, int do_expand, int do_select, hipStream_t st) {
+    const dim3 grid((e.num_games + 3) / 4), block(256);
+    if (g_step_variant == 1) hipLaunchKernelGGL(engine_step_fast_kernel<N>, grid, block, 0, st, e, do_expand, do_select, g_step_fast_depth);
+    else hipLaunchKernelGGL(engine_step_kernel<N>, grid, block, 0, st, e, do_expand, do_select);
+}
+
 // ------------------------------------------------------------------------------------------------
 // finish move: visits -> policy (pv_mcts.py:88-95), record, np.random.choice, next(), terminal handling
 // ------------------------------------------------------------------------------------------------
@@ -386,14 +687,15 @@ __global__ __launch_bounds__(256) void engine_finish_move_kernel(aqg_engine e, c
     const NodeRec* __restrict__ nodes = game_nodes(e, g);
     const uint32_t kids = nodes[0].kids;
     const int cnt = (int)(kids >> 24), first = (int)(kids & 0xFFFFFF);
-    const int ply = e.game_plies[g];
+    const int k = e.slot_game[g];                  // history, plies and result are kept per GAME: a slot plays several
+    const int ply = e.game_plies[k];
     QState s = load_state(e.root_state, 1, g);
 
     // history row: state72 + dense visit counts
     if (ply < e.max_plies) {
-        uint8_t* hs = e.hist_state72 + ((size_t)g * e.max_plies + ply) * STATE72;
+        uint8_t* hs = e.hist_state72 + ((size_t)k * e.max_plies + ply) * STATE72;
         if (lane == 0) pack72(s, N, hs);
-        uint16_t* hv = e.hist_visits + ((size_t)g * e.max_plies + ply) * A;
+        uint16_t* hv = e.hist_visits + ((size_t)k * e.max_plies + ply) * A;
         for (int i = lane; i < cnt; i += 64) hv[nodes[first + i].action] = (uint16_t)nodes[first + i].n;
     }
     if (lane != 0) return;
@@ -433,23 +735,78 @@ __global__ __launch_bounds__(256) void engine_finish_move_kernel(aqg_engine e, c
     if (chosen < 0) {
         // Dead end: legal_actions() is empty.  The reference would re-predict forever-leaf and np.random.choice([])
         // raises; we abort the game as a draw and count it.
-        e.game_active[g] = 0; e.game_result[g] = 0;
+        e.game_active[g] = 0; e.game_result[k] = 0; e.game_done[k] = 1;
         atomicAdd(&e.counters[2], 1); atomicAdd(&e.counters[1], 1); atomicSub(&e.counters[0], 1);
         return;
     }
-    if (ply < e.max_plies) e.hist_action[(size_t)g * e.max_plies + ply] = (uint8_t)chosen;
+    if (ply < e.max_plies) e.hist_action[(size_t)k * e.max_plies + ply] = (uint8_t)chosen;
     const QState t = next_state<N>(s, chosen);
     store_state(e.root_state, g, t);
-    e.game_plies[g] = ply + 1;
+    e.game_plies[k] = ply + 1;
     const bool lose = is_lose<N>(t), draw = is_draw(t, e.plies_for_draw);
     if (lose || draw) {
         // first_player_value (self_play.py:22-27): ended state's mover lost; z of ply 0, alternating afterwards (:63-66)
         int z = 0;
         if (lose) z = ((t.plies % 2) == 0) ? -1 : 1;
-        e.game_result[g] = (int8_t)z;
-        e.game_active[g] = 0;
+        e.game_result[k] = (int8_t)z;
+        e.game_done[k] = 1;
+        e.game_active[g] = 0;                  // engine_refill_kernel may hand the slot its next game
         atomicAdd(&e.counters[1], 1); atomicSub(&e.counters[0], 1);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// slot refill: a rank plays a QUOTA of games on its G slots (the reference's plain loop over games, self_play.py:81-84).
+// After every move the idle slots -- in slot order, so that the assignment is deterministic -- take the next game
+// indices not yet handed out and start from the initial position; once the quota is exhausted a finished slot stays
+// idle.  One workgroup: a block-wide exclusive scan over the slots' "idle" flags.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void engine_refill_kernel(aqg_engine e) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) base = e.counters[3];
+    __syncthreads();
+    const int move_index = e.counters[4] + 1;               // counters[4] = moves finished before this one; new games join the next
+    __syncthreads();
+    for (int g0 = 0; g0 < e.num_games; g0 += 1024) {
+        const int g = g0 + tid;
+        const int idle = (g < e.num_games && !e.game_active[g] && e.slot_game[g] >= 0) ? 1 : 0;
+        int x = idle;                                        // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int i = 0; i < 16; ++i) { if (i < w) before += wsum[i]; total += wsum[i]; }
+        const int k = base + before + x - idle;              // this slot's next game, if any is left
+        if (idle) {
+            if (k < e.quota) {
+                const int N = e.board_size;
+                QState s;
+                s.hw = 0; s.vw = 0;
+                s.ppos = (uint8_t)(N * (N - 1) + N / 2); s.pwl = (uint8_t)e.num_walls;
+                s.epos = s.ppos; s.ewl = s.pwl;
+                s.plies = 0; s.pad = 0;
+                store_state(e.root_state, g, s);
+                e.slot_game[g] = k;
+                e.game_slot[k] = g;
+                e.game_first_move[k] = move_index;
+                e.game_active[g] = 1;
+                e.leaf_flag[g] = 0;
+            } else {
+                e.slot_game[g] = -1;                         // retired
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int handed = min(total, max(e.quota - base, 0));
+            base += total;
+            if (handed) atomicAdd(&e.counters[0], handed);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { e.counters[3] = min(base, e.quota); e.counters[4] = move_index; }
 }
 
 template <int N>
@@ -478,26 +835,30 @@ static int validate(const aqg_engine& e) {
     if ((long long)e.node_cap >= (1 << 24)) return fail("node_cap must be < 2^24");
     if (e.node_cap < 1 + MAX_LEGAL) return fail("node_cap too small");
     if (e.prior_mode == 0 && N != 9 && !e.gnn_workspace) return fail("boards other than 9x9 need gnn_workspace for the GNN evaluator");
+    if (e.prior_mode < 0 || e.prior_mode > 2) return fail("prior_mode must be 0, 1 or 2");
+    if (e.quota < e.num_games) return fail("quota must be >= num_games");
+    if (!e.slot_game || !e.game_done || !e.game_slot || !e.game_first_move) return fail("slot_game / game_done / game_slot / game_first_move are required");
     return 0;
 }
 
 template <int N>
 static int enqueue_sims(const aqg_engine& e, hipStream_t st) {
+    if (e.prior_mode == 2) return fail("prior_mode 2 (external evaluator): drive the move with aqg_engine_begin_move / _step / _finish_move");
     const dim3 grid((e.num_games + 3) / 4), block(256);
     hipLaunchKernelGGL(engine_begin_move_kernel, dim3((e.num_games + 255) / 256), dim3(256), 0, st, e);
     for (int sim = 0; sim < e.sims; ++sim) {
-        hipLaunchKernelGGL(engine_step_kernel<N>, grid, block, 0, st, e, sim > 0 ? 1 : 0, 1);
+        launch_step<N>(e, sim > 0 ? 1 : 0, 1, st);
         if (e.prior_mode == 0) {
             // 9x9: the fused trunk; smaller boards: plain kernels over e.gnn_workspace
             if (int r = launch_gcn_forward_boards_any(N, e.leaf_state, 1, e.num_games, e.packed_weights, e.gnn_workspace,
                                                       e.gnn_workspace ? boards_any_workspace_floats(N, e.num_games) : 0, e.pooled, nullptr,
-                                                      e.policy, nullptr, e.value, e.leaf_flag, st))
+                                                      e.policy, nullptr, e.value, e.leaf_flag, e.gnn_flags, st))
                 return r;
         } else {
             hipLaunchKernelGGL(engine_fake_eval_kernel<N>, grid, block, 0, st, e);
         }
     }
-    hipLaunchKernelGGL(engine_step_kernel<N>, grid, block, 0, st, e, 1, 0);   // expand + backup of the last simulation
+    launch_step<N>(e, 1, 0, st);   // expand + backup of the last simulation
     return check_launch("engine simulation kernels");
 }
 
@@ -509,7 +870,7 @@ static int enqueue_sims(const aqg_engine& e, hipStream_t st) {
 // below and the library's other host-side globals are not synchronised.)
 struct SimGraph {
     aqg_engine e;
-    int opts[4];
+    int opts[7];
     hipGraphExec_t exec;
 };
 static std::vector<SimGraph> g_sim_graphs;
@@ -517,7 +878,8 @@ static std::vector<SimGraph> g_sim_graphs;
 template <int N>
 static int run_sims(const aqg_engine& e, hipStream_t st) {
     if (!g_use_graph || g_profile_trunk || st == nullptr || e.sims < 4) return enqueue_sims<N>(e, st);
-    const int opts[4] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, N};
+    // every option a captured launch bakes in is part of the key: a changed option must never replay a stale graph
+    const int opts[7] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth};
     for (const SimGraph& g : g_sim_graphs)
         if (!memcmp(&g.e, &e, sizeof(aqg_engine)) && !memcmp(g.opts, opts, sizeof(opts))) {
             if (hipGraphLaunch(g.exec, st) != hipSuccess) return fail("hipGraphLaunch");
@@ -539,6 +901,7 @@ static int run_sims(const aqg_engine& e, hipStream_t st) {
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) return fail("hipGraphInstantiate");
     if (g_sim_graphs.size() >= 16) {                         // small FIFO cache: engines come and go
+        (void)hipDeviceSynchronize();                        // the evicted exec may still be replaying on another stream
         (void)hipGraphExecDestroy(g_sim_graphs.front().exec);
         g_sim_graphs.erase(g_sim_graphs.begin());
     }
@@ -551,12 +914,48 @@ template <int N>
 static int do_move(const aqg_engine& e, const double* uniforms, hipStream_t st) {
     if (int r = run_sims<N>(e, st)) return r;
     hipLaunchKernelGGL(engine_finish_move_kernel<N>, dim3((e.num_games + 3) / 4), dim3(256), 0, st, e, uniforms);
+    if (e.quota > e.num_games) hipLaunchKernelGGL(engine_refill_kernel, dim3(1), dim3(1024), 0, st, e);
+    return check_launch("engine_finish_move_kernel");
+}
+
+// External-evaluator mode (prior_mode 2): the caller runs the simulation loop itself -- begin, then per simulation
+// step(expand the previous leaf, select the next) -> its OWN evaluator fills policy[g][0 .. legal_count[g]) (a PMF over
+// legal_actions() in order, the BaseNetwork.predict contract BaseNetwork.py:36-40) and value[g] for every game with
+// leaf_flag[g] == 1 -> ... -> step(expand, no select) -> finish.  Same kernels, same per-game semantics; the library
+// merely launches no evaluator between the steps.
+int engine_begin_move(const aqg_engine& e, hipStream_t st) {
+    if (int r = validate(e)) return r;
+    hipLaunchKernelGGL(engine_begin_move_kernel, dim3((e.num_games + 255) / 256), dim3(256), 0, st, e);
+    return check_launch("engine_begin_move_kernel");
+}
+
+int engine_step(const aqg_engine& e, int do_expand, int do_select, hipStream_t st) {
+    if (int r = validate(e)) return r;
+    switch (e.board_size) {
+        case 3: launch_step<3>(e, do_expand, do_select, st); break;
+        case 5: launch_step<5>(e, do_expand, do_select, st); break;
+        case 7: launch_step<7>(e, do_expand, do_select, st); break;
+        default: launch_step<9>(e, do_expand, do_select, st); break;
+    }
+    return check_launch("engine_step_kernel");
+}
+
+int engine_finish_move(const aqg_engine& e, const double* uniforms, hipStream_t st) {
+    if (int r = validate(e)) return r;
+    const dim3 grid((e.num_games + 3) / 4), block(256);
+    switch (e.board_size) {
+        case 3: hipLaunchKernelGGL(engine_finish_move_kernel<3>, grid, block, 0, st, e, uniforms); break;
+        case 5: hipLaunchKernelGGL(engine_finish_move_kernel<5>, grid, block, 0, st, e, uniforms); break;
+        case 7: hipLaunchKernelGGL(engine_finish_move_kernel<7>, grid, block, 0, st, e, uniforms); break;
+        default: hipLaunchKernelGGL(engine_finish_move_kernel<9>, grid, block, 0, st, e, uniforms); break;
+    }
+    if (e.quota > e.num_games) hipLaunchKernelGGL(engine_refill_kernel, dim3(1), dim3(1024), 0, st, e);
     return check_launch("engine_finish_move_kernel");
 }
 
 int engine_reset(const aqg_engine& e, hipStream_t st) {
     if (int r = validate(e)) return r;
-    hipLaunchKernelGGL(engine_reset_kernel, dim3((e.num_games + 255) / 256), dim3(256), 0, st, e);
+    hipLaunchKernelGGL(engine_reset_kernel, dim3((max(e.num_games, e.quota) + 255) / 256), dim3(256), 0, st, e);
     return check_launch("engine_reset_kernel");
 }
 
@@ -568,6 +967,12 @@ int engine_move(const aqg_engine& e, const double* uniforms, hipStream_t st) {
         case 7: return do_move<7>(e, uniforms, st);
         default: return do_move<9>(e, uniforms, st);
     }
+}
+
+int engine_set_roots(const aqg_engine& e, const uint8_t* roots72, hipStream_t st) {
+    if (int r = validate(e)) return r;
+    hipLaunchKernelGGL(engine_set_roots_kernel, dim3((e.num_games + 255) / 256), dim3(256), 0, st, e, roots72);
+    return check_launch("engine_set_roots_kernel");
 }
 
 int engine_search(const aqg_engine& e, const uint8_t* roots72, hipStream_t st) {

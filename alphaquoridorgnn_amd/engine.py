@@ -20,22 +20,31 @@ from .constants import BOARD_SIZE, board_params
 
 class BatchedSelfPlay:
     def __init__(self, model=None, num_games=2048, sims=50, board_size=BOARD_SIZE, device=None, temperature=1.0,
-                 c_puct=1.25, evaluator="gnn", fake_bias=0, seed=0, record_history=True):
+                 c_puct=1.25, evaluator="gnn", fake_bias=0, seed=0, record_history=True, quota=None):
         """model: GraphPolicyValueNetwork/GNNNetwork (evaluator='gnn'); evaluator='fake' runs the integer-hash
-        evaluator used by the parity tests (oracle/mcts.py FakeModel)."""
+        evaluator used by the parity tests (oracle/mcts.py FakeModel); evaluator='external' calls `model.predict(state,
+        device)` -- ANY object honouring the reference's BaseNetwork contract (BaseNetwork.py:36-40), e.g. a stock CNN --
+        once per simulation and game from the host, exactly like pv_mcts.py:47 (plumbing path: one host round trip per
+        simulation)."""
         self.dev = _lib.require_gpu(device)
         self.lib = _lib.load()
         self.N = board_size
         self.A = board_size ** 2 + 2 * (board_size - 1) ** 2
         self.num_walls, self.plies_for_draw = board_params(board_size)
         self.G, self.sims = int(num_games), int(sims)
+        # quota > G: the slots are refilled -- a slot whose game has ended takes the next game not yet handed out (in slot
+        # order, deterministic) until `quota` games have been started: the reference's loop over games (self_play.py:81-84)
+        # on G concurrent slots instead of lock-step generations that idle every finished slot until the longest game ends
+        self.quota = self.G if quota is None else int(quota)
+        if self.quota < self.G:
+            raise ValueError("quota must be >= num_games")
         self.node_cap = 1 + self.sims * _lib.MAX_LEGAL
         self.max_plies = self.plies_for_draw
         self.model = model
         self.evaluator = evaluator
         self.gen = torch.Generator(device=self.dev)
         self.gen.manual_seed(int(seed))
-        G, cap, dev = self.G, self.node_cap, self.dev
+        G, cap, dev, Q = self.G, self.node_cap, self.dev, self.quota
 
         def z(shape, dtype):
             return torch.zeros(shape, dtype=dtype, device=dev)
@@ -49,17 +58,21 @@ class BatchedSelfPlay:
         t["leaf_flag"] = z((G,), torch.uint8)
         t["leaf_state"] = z((G, 24), torch.uint8)
         t["game_active"] = z((G,), torch.uint8)
-        t["game_plies"] = z((G,), torch.int32)
-        t["game_result"] = z((G,), torch.int8)
+        t["slot_game"] = z((G,), torch.int32)
+        t["game_plies"] = z((Q,), torch.int32)
+        t["game_result"] = z((Q,), torch.int8)
+        t["game_done"] = z((Q,), torch.uint8)
+        t["game_slot"] = z((Q,), torch.int32)
+        t["game_first_move"] = z((Q,), torch.int32)
         t["legal_order"] = z((G, _lib.MAX_LEGAL), torch.uint8)
         t["legal_count"] = z((G,), torch.int32)
         t["pooled"] = z((G, 128), torch.float32)
         t["policy"] = z((G, self.A), torch.float32)   # also holds the fake evaluator's legal-ordered priors (count <= A)
         t["value"] = z((G,), torch.float32)
         hp = self.max_plies if record_history else 1
-        t["hist_state72"] = z((G, hp, 72), torch.uint8)
-        t["hist_visits"] = z((G, hp, self.A), torch.int16)
-        t["hist_action"] = z((G, hp), torch.uint8)
+        t["hist_state72"] = z((Q, hp, 72), torch.uint8)
+        t["hist_visits"] = z((Q, hp, self.A), torch.int16)
+        t["hist_action"] = z((Q, hp), torch.uint8)
         t["counters"] = z((8,), torch.int32)
         t["stat_leaf_evals"] = z((G,), torch.int32)
         t["stat_terminal_sims"] = z((G,), torch.int32)
@@ -67,20 +80,26 @@ class BatchedSelfPlay:
             if model is None:
                 raise ValueError("evaluator='gnn' needs a model")
             t["packed_weights"] = model.packed_weights(dev)
+            self._gnn_flags = model.gnn_flags(dev)
             if self.N != 9:      # smaller boards run the any-size forward, which needs a caller-owned workspace
                 t["gnn_workspace"] = z((int(self.lib.aqg_gcn_boards_any_workspace_floats(self.N, G)),), torch.float32)
         else:
+            if evaluator == "external" and (model is None or not hasattr(model, "predict")):
+                raise ValueError("evaluator='external' needs a model with predict(state, device)")
             t["packed_weights"] = z((4,), torch.float32)
+            self._gnn_flags = 0
 
         e = self.e = _lib.EngineStruct()
         e.board_size, e.num_walls, e.plies_for_draw = self.N, self.num_walls, self.plies_for_draw
-        e.num_games, e.sims, e.node_cap = G, self.sims, cap
+        e.num_games, e.quota, e.sims, e.node_cap = G, Q, self.sims, cap
         e.max_plies = hp if record_history else 0
-        e.prior_mode = 0 if evaluator == "gnn" else 1
+        e.prior_mode = {"gnn": 0, "fake": 1, "external": 2}[evaluator]
         e.fake_bias = int(fake_bias)
+        e.gnn_flags = int(self._gnn_flags)
         e.c_puct, e.temperature = float(c_puct), float(temperature)
         for name in ("node_rec", "node_count", "root_state", "path",
-                     "path_len", "leaf_flag", "leaf_state", "game_active", "game_plies", "game_result", "legal_order",
+                     "path_len", "leaf_flag", "leaf_state", "game_active", "slot_game", "game_plies", "game_result", "game_done",
+                     "game_slot", "game_first_move", "legal_order",
                      "legal_count", "pooled", "policy", "value", "hist_state72", "hist_visits", "hist_action", "counters",
                      "stat_leaf_evals", "stat_terminal_sims", "packed_weights"):
             setattr(e, name, t[name].data_ptr())
@@ -101,6 +120,7 @@ class BatchedSelfPlay:
         if self.evaluator == "gnn":
             self.t["packed_weights"] = self.model.packed_weights(self.dev)
             self.e.packed_weights = self.t["packed_weights"].data_ptr()
+            self.e.gnn_flags = int(self.model.gnn_flags(self.dev))
 
     def move(self, uniforms=None):
         """One move for every active game.  uniforms: float64 [G] in [0,1) (default: device RNG stream)."""
@@ -109,24 +129,67 @@ class BatchedSelfPlay:
         else:
             uniforms = torch.as_tensor(uniforms, dtype=torch.float64).to(self.dev).contiguous()
         self._u = uniforms  # keep alive until the stream has consumed it
-        _lib.check(self.lib.aqg_engine_move(ctypes.byref(self.e), _lib.ptr(uniforms), self._stream()), "aqg_engine_move")
+        if self.evaluator == "external":
+            self._external_sims()
+            _lib.check(self.lib.aqg_engine_finish_move(ctypes.byref(self.e), _lib.ptr(uniforms), self._stream()), "aqg_engine_finish_move")
+        else:
+            _lib.check(self.lib.aqg_engine_move(ctypes.byref(self.e), _lib.ptr(uniforms), self._stream()), "aqg_engine_move")
         self.moves_done += 1
+
+    # ------------------------------------------------------------------ external evaluator (prior_mode 2)
+    def _leaf_states(self, idx):
+        """game_logic.State objects of the leaves of games `idx` (24-byte packed records: wall masks, pawns, plies)."""
+        from .game_logic import State
+        raw = self.t["leaf_state"][idx].cpu().numpy().view(np.uint64).reshape(-1, 3)
+        nw = (self.N - 1) ** 2
+        out = []
+        for hw, vw, m in raw:
+            hw, vw, m = int(hw), int(vw), int(m)
+            walls = [(1 if (hw >> i) & 1 else 0) + (2 if (vw >> i) & 1 else 0) for i in range(nw)]
+            out.append(State(board_size=self.N, player=[m & 0xFF, (m >> 8) & 0xFF], enemy=[(m >> 16) & 0xFF, (m >> 24) & 0xFF],
+                             walls=walls, plies_played=(m >> 32) & 0xFFFF))
+        return out
+
+    def _external_sims(self, device=None):
+        """pv_mcts.py:84-85 with the caller's model: per simulation the engine selects a leaf per game, the host asks
+        model.predict(state, device) for each (pv_mcts.py:47) and hands the PMF over the leaf's legal actions + the value back."""
+        e, st = ctypes.byref(self.e), self._stream()
+        _lib.check(self.lib.aqg_engine_begin_move(e, st), "aqg_engine_begin_move")
+        for sim in range(self.sims):
+            _lib.check(self.lib.aqg_engine_step(e, 1 if sim else 0, 1, st), "aqg_engine_step")
+            idx = torch.nonzero(self.t["leaf_flag"] == 1).flatten()
+            if idx.numel() == 0:
+                continue
+            counts = self.t["legal_count"][idx].cpu().numpy()
+            pol = torch.zeros((idx.numel(), self.A), dtype=torch.float32)
+            val = torch.zeros((idx.numel(),), dtype=torch.float32)
+            for j, state in enumerate(self._leaf_states(idx)):
+                p, v = self.model.predict(state, device if device is not None else "cpu")
+                p = np.asarray(p, dtype=np.float32)
+                if p.shape[0] != counts[j]:
+                    raise ValueError("model.predict must return one prior per legal action (BaseNetwork.py:36-40)")
+                pol[j, :p.shape[0]] = torch.from_numpy(p)
+                val[j] = float(v)
+            self.t["policy"][idx] = pol.to(self.dev)
+            self.t["value"][idx] = val.to(self.dev)
+        _lib.check(self.lib.aqg_engine_step(e, 1, 0, st), "aqg_engine_step")
 
     def counters(self):
         c = self.t["counters"].cpu().numpy()
-        return dict(active=int(c[0]), finished=int(c[1]), dead_ends=int(c[2]),
+        return dict(active=int(c[0]), finished=int(c[1]), dead_ends=int(c[2]), started=int(c[3]), moves=int(c[4]),
                     leaf_evals=int(self.t["stat_leaf_evals"].sum().item()),
                     terminal_sims=int(self.t["stat_terminal_sims"].sum().item()))
 
     def play_generation(self, uniforms=None, check_every=4):
-        """Play every slot to termination (one self_play generation's worth of games on this rank).
-        uniforms: optional float64 [max_plies, G] (parity tests).  Returns the counters dict."""
+        """Play the whole quota (== every slot once when quota == num_games: one self_play generation's worth of games
+        on this rank).  uniforms: optional float64 [moves, G] (parity tests).  Returns the counters dict."""
         ply = 0
+        limit = self.max_plies * (-(-self.quota // self.G))          # every slot plays at most ceil(quota / G) games
         while True:
             self.move(None if uniforms is None else uniforms[ply])
             ply += 1
-            if ply >= self.max_plies or ply % check_every == 0:
-                if self.counters()["active"] == 0 or ply >= self.max_plies:
+            if ply >= limit or ply % check_every == 0:
+                if self.counters()["active"] == 0 or ply >= limit:
                     break
         return self.counters()
 
@@ -134,7 +197,11 @@ class BatchedSelfPlay:
     def search(self, root_states72):
         roots = torch.as_tensor(root_states72, dtype=torch.uint8).to(self.dev).contiguous().view(self.G, 72)
         self._roots = roots
-        _lib.check(self.lib.aqg_engine_search(ctypes.byref(self.e), _lib.ptr(roots), self._stream()), "aqg_engine_search")
+        if self.evaluator == "external":
+            _lib.check(self.lib.aqg_engine_set_roots(ctypes.byref(self.e), _lib.ptr(roots), self._stream()), "aqg_engine_set_roots")
+            self._external_sims()
+        else:
+            _lib.check(self.lib.aqg_engine_search(ctypes.byref(self.e), _lib.ptr(roots), self._stream()), "aqg_engine_search")
         visits = torch.empty((self.G, _lib.MAX_LEGAL), dtype=torch.int32, device=self.dev)
         actions = torch.empty((self.G, _lib.MAX_LEGAL), dtype=torch.uint8, device=self.dev)
         count = torch.empty((self.G,), dtype=torch.int32, device=self.dev)
@@ -144,11 +211,12 @@ class BatchedSelfPlay:
 
     # ------------------------------------------------------------------ history
     def history_tensors(self):
-        """(states72 u8 [P,72], visits i16 [P,A], z i8 [P]) for all finished games on this rank, game-major."""
+        """(states72 u8 [P,72], visits i16 [P,A], z i8 [P]) for all finished games on this rank, game-major (game index =
+        order in which the games were started)."""
         plies = self.t["game_plies"].long()
         hp = self.t["hist_state72"].shape[1]
         idx = torch.arange(hp, device=self.dev).unsqueeze(0)
-        valid = (idx < plies.unsqueeze(1)) & (self.t["game_active"] == 0).unsqueeze(1)
+        valid = (idx < plies.unsqueeze(1)) & (self.t["game_done"] != 0).unsqueeze(1)
         z0 = self.t["game_result"].to(torch.int8).unsqueeze(1)
         sign = torch.where(idx % 2 == 0, 1, -1).to(torch.int8)      # z alternates down the history (self_play.py:63-66)
         z = (z0 * sign)[valid]
@@ -182,20 +250,29 @@ class MultiSetSelfPlay:
     bit-identical to a stand-alone BatchedSelfPlay(num_games_k, seed = seed * 64 + k): nothing is shared but the
     read-only packed weights."""
 
-    def __init__(self, model=None, num_games=2048, sims=50, num_sets=None, seed=0, device=None, **kw):
+    def __init__(self, model=None, num_games=2048, sims=50, num_sets=None, seed=0, device=None, quota=None, **kw):
         self.dev = _lib.require_gpu(device)
         if num_sets is None:                      # one hardware queue per set + the default stream, or fall back to 2
             num_sets = 4 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 5 else 2
         k = max(1, min(int(num_sets), int(num_games)))
         sizes = [num_games // k + (1 if i < num_games % k else 0) for i in range(k)]
+        quota = num_games if quota is None else int(quota)
+        quotas = [quota // k + (1 if i < quota % k else 0) for i in range(k)]      # each set refills its own slots
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in sizes]
         self.sets = []
         ready = torch.cuda.current_stream(self.dev).record_event()   # e.g. the model's weight upload on the caller's stream
         for i, g in enumerate(sizes):
             with torch.cuda.stream(self.streams[i]):
                 self.streams[i].wait_event(ready)
-                self.sets.append(BatchedSelfPlay(model, num_games=g, sims=sims, seed=int(seed) * 64 + i, device=self.dev, **kw))
+                self.sets.append(BatchedSelfPlay(model, num_games=g, sims=sims, seed=int(seed) * 64 + i, device=self.dev,
+                                                 quota=max(quotas[i], g), **kw))
         self.G, self.sims = int(num_games), int(sims)
+        # quota > G: the slots are refilled -- a slot whose game has ended takes the next game not yet handed out (in slot
+        # order, deterministic) until `quota` games have been started: the reference's loop over games (self_play.py:81-84)
+        # on G concurrent slots instead of lock-step generations that idle every finished slot until the longest game ends
+        self.quota = self.G if quota is None else int(quota)
+        if self.quota < self.G:
+            raise ValueError("quota must be >= num_games")
         self.max_plies = self.sets[0].max_plies
         self.A, self.N = self.sets[0].A, self.sets[0].N
         self._live = [True] * k
@@ -243,7 +320,7 @@ class MultiSetSelfPlay:
         return self._live[k]
 
     def counters(self):
-        tot = dict(active=0, finished=0, dead_ends=0, leaf_evals=0, terminal_sims=0)
+        tot = dict(active=0, finished=0, dead_ends=0, started=0, moves=0, leaf_evals=0, terminal_sims=0)
         for i, eng in self._each():
             c = eng.counters()                    # .cpu() inside synchronises this set's stream only
             self._live[i] = self._live[i] and c["active"] > 0
@@ -253,11 +330,12 @@ class MultiSetSelfPlay:
 
     def play_generation(self, check_every=4):
         ply = 0
+        limit = self.max_plies * max(-(-e.quota // e.G) for e in self.sets)
         while True:
             self.move()
             ply += 1
-            if ply >= self.max_plies or ply % check_every == 0:
-                if self.counters()["active"] == 0 or ply >= self.max_plies:
+            if ply >= limit or ply % check_every == 0:
+                if self.counters()["active"] == 0 or ply >= limit:
                     break
         return self.counters()
 

@@ -73,11 +73,13 @@ class BatchedMatch:
         if evaluator == "gnn":
             dev = next(e for e in self.engines if e is not None).dev
             self._packed = [m.packed_weights(dev) for m in players]
+            self._flags = [int(m.gnn_flags(dev)) for m in players]
 
     def _point_at(self, eng, mover):
         if self.evaluator == "gnn":
             eng.t["packed_weights"] = self._packed[mover]
             eng.e.packed_weights = self._packed[mover].data_ptr()
+            eng.e.gnn_flags = self._flags[mover]
         else:
             eng.e.fake_bias = int(self.players[mover])
 

@@ -23,7 +23,7 @@ def _engine_for(model, num_games, sims, board_size, evaluator="gnn", fake_bias=0
             _engines.clear()
         eng = _engines[key] = BatchedSelfPlay(model, num_games=num_games, sims=sims, board_size=board_size,
                                               evaluator=evaluator, fake_bias=fake_bias, record_history=False)
-    else:
+    elif evaluator == "gnn":
         eng.refresh_weights()
     return eng
 
@@ -53,10 +53,16 @@ def pv_mcts_policy_batch(model, states72, temperature, sims=None, board_size=Non
     return [_policy_from_visits([int(v) for v in visits[b, :count[b]]], temperature) for b in range(B)]
 
 
+def evaluator_of(model):
+    """'gnn' for the network the HIP kernels evaluate themselves; 'external' for any other object with the reference's
+    predict(state, device) (BaseNetwork.py:36-40) -- e.g. the CNN the reference wires (self_play.py:16,78)."""
+    return "gnn" if hasattr(model, "packed_weights") else "external"
+
+
 def pv_mcts_policy(model, state, temperature, device=None):
     """PUCT MCTS from `state`; returns the improved policy over state.legal_actions() (pv_mcts.py:20-95)."""
     rec = torch.from_numpy(state.record()).unsqueeze(0)
-    return pv_mcts_policy_batch(model, rec, temperature, PV_EVALUATE_COUNT, state.N)[0]
+    return pv_mcts_policy_batch(model, rec, temperature, PV_EVALUATE_COUNT, state.N, evaluator=evaluator_of(model))[0]
 
 
 def pv_mcts_action(model, temperature=0, device='cpu'):

@@ -76,10 +76,12 @@ class GraphPolicyValueNetwork(nn.Module):
                                         nn.Linear(hidden_dim // 2, 1), nn.Tanh())
         self._packed = None
         self._packed_key = None
+        self._gnn_flags = 0
 
     # ---------------------------------------------------------------- weight packing
     def packed_weights(self, device):
-        """float32 device buffer in the kernel layout (include/aqgnn.h); rebuilt when a parameter changes."""
+        """float32 device buffer in the kernel layout (include/aqgnn.h); rebuilt when a parameter changes.  Every rebuild
+        also re-runs the fp16-range check of this weight set (`gnn_flags`)."""
         sd = self.state_dict()
         key = (str(device),) + tuple((sd[k].data_ptr(), sd[k]._version) for k in STATE_DICT_KEYS)
         if self._packed is None or key != self._packed_key:
@@ -91,6 +93,7 @@ class GraphPolicyValueNetwork(nn.Module):
                        "aqg_gcn_pack_weights_host")
             self._packed = out.to(device)
             self._packed_key = key
+            self._gnn_flags = self._calibrate(self._packed, device)
         return self._packed
 
     def invalidate_packed(self):
@@ -98,6 +101,55 @@ class GraphPolicyValueNetwork(nn.Module):
         a HIP kernel, which does not bump the tensors' version counters)."""
         self._packed = None
         self._packed_key = None
+
+    def gnn_flags(self, device):
+        """Flags every GNN forward of this weight set must carry (0, or _lib.GNN_EXACT_F32 when the fp16-split kernels
+        cannot represent its activations: see _calibrate)."""
+        self.packed_weights(device)
+        return self._gnn_flags
+
+    _calib_boards = {}
+
+    @classmethod
+    def _calibration_boards(cls, device):
+        """64 synthetic 9x9 boards spanning the feature range (pawns anywhere, 0..10 walls in hand, 0..20 walls on the
+        board, not necessarily legal positions: only the network sees them), plus the start position."""
+        key = str(device)
+        if key not in cls._calib_boards:
+            rng = np.random.RandomState(20250117)
+            recs = np.zeros((64, 72), dtype=np.uint8)
+            for i in range(64):
+                recs[i, 0], recs[i, 2] = rng.randint(0, 81, 2)
+                recs[i, 1], recs[i, 3] = (10, 10) if i < 8 else rng.randint(0, 11, 2)
+                nw = 0 if i == 0 else rng.randint(0, 21)
+                recs[i, 4 + rng.choice(64, nw, replace=False)] = rng.randint(1, 3, nw)
+                recs[i, 70] = 9
+            recs[0, 0] = recs[0, 2] = 76
+            cls._calib_boards[key] = torch.from_numpy(recs).to(device)
+        return cls._calib_boards[key]
+
+    def _calibrate(self, packed, device):
+        """The default trunk / heads hold every activation as TWO fp16 numbers (hi + lo: fp32-equivalent products on the
+        16-bit matrix pipe).  That is exact-enough only while activations stay inside fp16 range; beyond it the kernels
+        saturate at 65504 instead of overflowing -- finite, but no longer the network.  The reference's fp32 has no such
+        limit, so each weight set is checked once: both kernel families run on the calibration boards, and if their logits
+        or values disagree beyond rounding the weight set is served by the exact f32-input MFMA kernels from then on."""
+        if self.board_size != 9:
+            return 0                                      # smaller boards run the plain f32 kernels anyway
+        lib = _lib.load()
+        boards = self._calibration_boards(device)
+        B, A = boards.shape[0], self.policy_output_size
+        res = []
+        for flags in (0, _lib.GNN_EXACT_F32):
+            pooled = torch.empty((B, HIDDEN_DIM), dtype=torch.float32, device=device)
+            logits = torch.empty((B, A), dtype=torch.float32, device=device)
+            vpre = torch.empty((B,), dtype=torch.float32, device=device)
+            _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(boards), 0, B, _lib.ptr(packed), _lib.ptr(pooled), _lib.ptr(logits),
+                                                  None, _lib.ptr(vpre), None, flags, _lib.stream_ptr(device)), "calibration forward")
+            res.append(torch.cat([logits, vpre.unsqueeze(1)], 1).double())
+        split, exact = res
+        ok = bool(((split - exact).abs() <= 1e-4 + 1e-3 * exact.abs()).all())    # NaN compares False
+        return 0 if ok else _lib.GNN_EXACT_F32
 
     # ---------------------------------------------------------------- fused board path
     def forward_states(self, states72, want_logits=False, state_fmt=0):
@@ -116,14 +168,15 @@ class GraphPolicyValueNetwork(nn.Module):
         if self.board_size == 9:
             _lib.check(lib.aqg_gcn_forward_boards(self.board_size, _lib.ptr(states72), state_fmt, B,
                                                   _lib.ptr(self.packed_weights(dev)), _lib.ptr(pooled), _lib.ptr(logits),
-                                                  _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value), _lib.stream_ptr(dev)),
+                                                  _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value), self.gnn_flags(dev),
+                                                  _lib.stream_ptr(dev)),
                        "aqg_gcn_forward_boards")
         else:   # the reference's smaller boards (constants.py:5-20): plain kernels over a caller-owned workspace
             nws = lib.aqg_gcn_boards_any_workspace_floats(self.board_size, B)
             ws = torch.empty((max(int(nws), 1),), **f32)
             _lib.check(lib.aqg_gcn_forward_boards_any(self.board_size, _lib.ptr(states72), state_fmt, B,
                                                       _lib.ptr(self.packed_weights(dev)), _lib.ptr(ws), nws, _lib.ptr(pooled),
-                                                      _lib.ptr(logits), _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value),
+                                                      _lib.ptr(logits), _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value), 0,
                                                       _lib.stream_ptr(dev)), "aqg_gcn_forward_boards_any")
         if want_logits:
             return policy, value.unsqueeze(1), logits, vpre

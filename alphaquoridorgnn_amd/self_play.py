@@ -54,19 +54,40 @@ def play(model, device=None, uniforms=None):
     """Execute one self-play game (self_play.py:40-68) -- a generation of one game on the engine.
     Returns [[state_array, policy list[POLICY_OUTPUT_SIZE], z], ...]."""
     eng = BatchedSelfPlay(model, num_games=1, sims=pv_mcts.PV_EVALUATE_COUNT, board_size=BOARD_SIZE,
-                          temperature=SP_TEMPERATURE, seed=int(np.random.randint(0, 2 ** 31 - 1)))
+                          temperature=SP_TEMPERATURE, seed=int(np.random.randint(0, 2 ** 31 - 1)),
+                          evaluator=pv_mcts.evaluator_of(model))
     eng.play_generation(uniforms=uniforms, check_every=1)
     return eng.history()
 
 
-def self_play(model=None, games=None):
-    """Perform self-play games and save the training data (self_play.py:71-95)."""
+def _fresh_seed():
+    """Base seed of one self_play() call.  The reference draws every move from the unseeded global numpy RNG
+    (self_play.py:57), so two generations never repeat; here the engine's uniform stream is seeded per call from
+    the same global RNG (or from AQG_SELFPLAY_SEED for reproducible runs).  Under torch.distributed rank 0's draw
+    is broadcast, and every rank adds its rank, so the ranks' streams differ and a rerun with the same override
+    reproduces the same generation."""
+    import torch.distributed as dist
+    env = os.environ.get("AQG_SELFPLAY_SEED")
+    seed = int(env) if env is not None else int(np.random.randint(0, 2 ** 31 - 1))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.tensor([seed], dtype=torch.int64, device=dev)
+        dist.broadcast(t, src=0)
+        seed = int(t.item())
+    return seed
+
+
+def self_play(model=None, games=None, seed=None):
+    """Perform self-play games and save the training data (self_play.py:71-95).  `seed` (tests) fixes the uniform
+    stream; by default every call draws a fresh one, like the reference's unseeded np.random.choice."""
     import torch.distributed as dist
     if model is None:
         model = GNNNetwork()
         model.prep_for_inference(model_path=PV_NETWORK_PATH + 'best.pth')
     total = SP_GAME_COUNT if games is None else games
-    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    distributed = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
+    base = _fresh_seed() if seed is None else int(seed)
     mine = total // world + (1 if rank < total % world else 0)
     st = torch.zeros((0, 72), dtype=torch.uint8, device='cuda')
     vis = torch.zeros((0, POLICY_OUTPUT_SIZE), dtype=torch.int16, device='cuda')
@@ -74,16 +95,23 @@ def self_play(model=None, games=None):
     if mine > 0:
         # >= 256 games: independent game sets on their own streams fill the holes of each other's serial kernel chains
         eng = MultiSetSelfPlay(model, num_games=mine, sims=pv_mcts.PV_EVALUATE_COUNT, num_sets=None if mine >= 256 else 1,
-                               board_size=BOARD_SIZE, temperature=SP_TEMPERATURE, seed=1234 + rank)
+                               board_size=BOARD_SIZE, temperature=SP_TEMPERATURE, seed=(base + rank) % (2 ** 31 - 1))
         c = eng.play_generation()
         print(f'\rSelf-play (rank {rank}: {c["finished"]}/{mine} games)', end='')
         st, vis, z = eng.history_tensors()
-    st, vis, z = gather_history(st, vis, z)
+    if distributed and dist.get_backend() != 'nccl':          # gloo (CPU tests): the exchange runs on host tensors
+        st, vis, z = (x.cpu() for x in gather_history(st.cpu(), vis.cpu(), z.cpu()))
+    else:
+        st, vis, z = gather_history(st, vis, z)
     print('')
+    path = None
     if rank == 0:
-        write_data(_history_rows(st, vis, z, BOARD_SIZE))
+        path = write_data(_history_rows(st, vis, z, BOARD_SIZE))
+    if distributed:
+        dist.barrier()          # no rank may go on to train_network.load_data() before rank 0 has finished the file
     del model
     torch.cuda.empty_cache()
+    return path
 
 
 if __name__ == '__main__':

@@ -153,7 +153,12 @@ def train_network():
         lr = LEARNING_RATE * lr_lambda(epoch)                                      # LambdaLR, stepped once per epoch (:98)
         perm = torch.randperm(n, device='cuda')                                    # DataLoader(shuffle=True), last batch kept
         if world > 1:
-            dist.broadcast(perm, src=0)
+            if dist.get_backend() == 'nccl':
+                dist.broadcast(perm, src=0)
+            else:                                                                  # gloo (tests): host tensors only
+                perm_h = perm.cpu()
+                dist.broadcast(perm_h, src=0)
+                perm = perm_h.to('cuda')
         epoch_policy_loss = torch.zeros((), device='cuda')
         epoch_value_loss = torch.zeros((), device='cuda')
         for i in range(0, n, BATCH_SIZE):
@@ -166,6 +171,8 @@ def train_network():
     if rank == 0:
         print('')
         torch.save(model.state_dict(), PV_NETWORK_PATH + 'latest.pth')
+    if world > 1:
+        dist.barrier()          # latest.pth is complete before any rank moves on to the evaluation stage
 
 
 if __name__ == '__main__':

@@ -182,7 +182,7 @@ def main():
 
     def fwd():
         _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(boards), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None,
-                                              _lib.ptr(value), _lib.stream_ptr(dev)), "fwd")
+                                              _lib.ptr(value), 0, _lib.stream_ptr(dev)), "fwd")
     variants = {}
     for name, v in (("f32_mfma_exact", 1), ("f16_split_mm_8wave_x2", 6), ("f16_split_mm_4wave_x3", 4)):
         _lib.set_option("trunk_variant", v)

@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define AQG_MAX_LEGAL 136 /* >= 5 pawn moves + 128 wall placements */
-#define AQG_ABI_VERSION 4
+#define AQG_ABI_VERSION 5
 
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
@@ -96,10 +96,16 @@ int aqg_gcn_pack_weights_host(int board_size, const float* const* tensors_host, 
  *   policy    [B,A]    Softmax output == module output (may be NULL)
  *   value_pre [B]      pre-tanh value (may be NULL)
  *   value     [B]      Tanh output == module output (may be NULL)
- * state_fmt: 0 = state72 records, 1 = 24-byte packed QState (engine-internal). */
+ * state_fmt: 0 = state72 records, 1 = 24-byte packed QState (engine-internal).
+ * flags: AQG_GNN_EXACT_F32 forces the exact f32-input MFMA trunk and the f32 heads for this call whatever "trunk_variant" says.
+ *   The fp16-split kernels hold every activation as two fp16 numbers: they are fp32-equivalent while all activations stay
+ *   inside fp16 range (|x| < 65504 -- true for any sanely scaled network, saturating instead of overflowing beyond), and the
+ *   host wrapper checks each weight set once against the exact kernels on calibration boards and sets this flag when they
+ *   disagree (pv_network_gnn.GraphPolicyValueNetwork.packed_weights). */
+#define AQG_GNN_EXACT_F32 1
 int aqg_gcn_forward_boards(int board_size, const void* states, int state_fmt, int B, const float* packed,
                            float* pooled, float* logits, float* policy, float* value_pre, float* value,
-                           void* stream);
+                           int flags, void* stream);
 
 /* Same network on an arbitrary batched graph: forward(x, edge_index, batch)  pv_network_gnn.py:53.
  *   x [num_nodes, F] f32;  csr_ptr [num_nodes+1] i32 / csr_src [E'] i32 / csr_w [E'] f32 : incoming edges of
@@ -112,7 +118,7 @@ int aqg_gcn_forward_boards(int board_size, const void* states, int state_fmt, in
 size_t aqg_gcn_boards_any_workspace_floats(int board_size, int B);
 int aqg_gcn_forward_boards_any(int board_size, const void* states, int state_fmt, int B, const float* packed, float* workspace,
                                size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre, float* value,
-                               void* stream);
+                               int flags, void* stream);
 
 int aqg_gcn_forward_graph(int num_features, int num_actions, const float* x, int num_nodes,
                           const int32_t* csr_ptr, const int32_t* csr_src, const float* csr_w,
@@ -127,12 +133,17 @@ int aqg_gcn_forward_graph(int num_features, int num_actions, const float* x, int
 typedef struct aqg_engine {
     int32_t board_size, num_walls, plies_for_draw;
     int32_t num_games;        /* G: concurrent game slots */
+    int32_t quota;            /* games to play on those slots in all, >= G: a finished slot takes the next game not yet handed out
+                                 (self_play.py:81-84 is a plain loop over games).  quota == G: one lock-step generation */
     int32_t sims;             /* PV_EVALUATE_COUNT  pv_mcts.py:18 */
     int32_t node_cap;         /* nodes per game tree >= 1 + sims * AQG_MAX_LEGAL */
     int32_t max_plies;        /* history rows per game slot (>= plies_for_draw) */
     int32_t prior_mode;       /* 0: network policy gathered at legal actions + renormalised (pv_network_cnn.py:129-132)
-                                 1: `fake` integer-hash evaluator (tests; oracle/mcts.py FakeModel) */
+                                 1: `fake` integer-hash evaluator (tests; oracle/mcts.py FakeModel)
+                                 2: external evaluator -- the caller's own model.predict (BaseNetwork.py:36-40) fills policy / value
+                                    between aqg_engine_step calls (see below) */
     int32_t fake_bias;
+    int32_t gnn_flags;        /* flags of the GNN forward for prior_mode 0 (AQG_GNN_EXACT_F32 or 0) */
     float c_puct;             /* 1.25  pv_mcts.py:71 */
     float temperature;        /* SP_TEMPERATURE self_play.py:20; 1.0 exact, 0 = argmax */
     /* tree pool: [G * node_cap] 32-byte node records {f64 w, f32 p, i32 n, u32 first_child|count<<24, u32 action, pad} */
@@ -140,14 +151,18 @@ typedef struct aqg_engine {
     /* per game, [G] */
     int32_t* node_count; uint8_t* root_state /* [G,24] */; int32_t* path /* [G, sims+2] */; int32_t* path_len;
     uint8_t* leaf_flag /* [G] 1 = this simulation's leaf needs an evaluation */; uint8_t* leaf_state /* [G,24] */;
-    uint8_t* game_active /* [G] */; int32_t* game_plies /* [G] rows recorded */; int8_t* game_result /* [G] z of ply 0, valid when inactive */;
+    uint8_t* game_active /* [G] slot is playing */; int32_t* slot_game /* [G] index of the game the slot is playing, -1 = retired */;
+    /* per game, [quota] */
+    int32_t* game_plies /* rows recorded */; int8_t* game_result /* z of ply 0 */; uint8_t* game_done /* 1 = finished */;
+    int32_t* game_slot /* slot that played / plays it, -1 = not started */; int32_t* game_first_move /* index of its first aqg_engine_move */;
     /* evaluation buffers, [G,...] */
     uint8_t* legal_order /* [G,AQG_MAX_LEGAL] */; int32_t* legal_count; float* pooled /* [G,128] */;
     float* policy /* [G,A] */; float* value /* [G] */;
-    /* history, per slot: [G, max_plies, ...] */
+    /* history, per game: [quota, max_plies, ...] */
     uint8_t* hist_state72; uint16_t* hist_visits /* [G,max_plies,A] root child visit counts, dense by action */;
     uint8_t* hist_action /* [G,max_plies] */;
-    /* counters [8] i32: 0 active games, 1 finished games, 2 dead-end aborts (updated once per move) */
+    /* counters [8] i32: 0 active slots, 1 finished games, 2 dead-end aborts, 3 next game index to hand out, 4 moves made
+     * (updated once per move) */
     int32_t* counters;
     /* per-game statistics [G] i32 (summed by the host): network evaluations, simulations that ended on a terminal node */
     int32_t* stat_leaf_evals; int32_t* stat_terminal_sims;
@@ -165,6 +180,18 @@ int aqg_engine_reset(const aqg_engine* e_host, void* stream);
  * apply next(); finished games get z (self_play.py:22-27,:63-66) and go inactive.
  *   uniforms [G] f64 in [0,1). */
 int aqg_engine_move(const aqg_engine* e_host, const double* uniforms, void* stream);
+/* The same move in pieces, for an evaluator the library does not own (prior_mode 2; pv_mcts.py:47 calls model.predict on
+ * whatever BaseNetwork it is given):
+ *     aqg_engine_begin_move
+ *     for sim in 0 .. sims-1:  aqg_engine_step(do_expand = sim > 0, do_select = 1)
+ *                              -> for every game with leaf_flag[g] == 1 the caller writes policy[g][0 .. legal_count[g]) = PMF over
+ *                                 the leaf's legal_actions() IN ORDER (legal_order[g]) and value[g]; leaf_state[g] is the 24-byte leaf
+ *     aqg_engine_step(1, 0); aqg_engine_finish_move(uniforms)        (or aqg_engine_root_visits for a search only)
+ * Per game exactly the reference's loop, one predict per simulation.  aqg_engine_set_roots installs caller-supplied roots. */
+int aqg_engine_begin_move(const aqg_engine* e_host, void* stream);
+int aqg_engine_step(const aqg_engine* e_host, int do_expand, int do_select, void* stream);
+int aqg_engine_finish_move(const aqg_engine* e_host, const double* uniforms, void* stream);
+int aqg_engine_set_roots(const aqg_engine* e_host, const uint8_t* root_states72, void* stream);
 /* pv_mcts_policy only, for caller-supplied root states (no history, no transition): after the call
  * node_n of the root's children holds the visit counts; `root_states72` [G,72]. */
 int aqg_engine_search(const aqg_engine* e_host, const uint8_t* root_states72, void* stream);

@@ -159,6 +159,7 @@ def test_gnn_forward_boards_vs_fp64_oracle(dev, variant):
     from oracle import gnn as og
     _lib.set_option("trunk_variant", variant)
     model, params = _model(0)
+    assert model.gnn_flags(dev) == 0     # the range guard must not have swapped the kernels under test for the exact ones
     g = U.golden("walk_9x9.npz")
     sel = np.linspace(0, g["states"].shape[0] - 1, 300).astype(int)
     recs = g["states"][sel]
@@ -193,6 +194,7 @@ def test_gnn_forward_scaled_weights(dev, variant):
     big["gcn_layers.1.bias"] = np.linspace(-0.5, 0.5, 128).astype(np.float32)
     big["gcn_layers.2.bias"] = np.linspace(0.3, -0.3, 128).astype(np.float32)
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in big.items()})
+    assert model.gnn_flags(dev) == 0
     g = U.golden("walk_9x9.npz")
     recs = g["states"][5000:5064]
     ref = og.forward_states(big, recs)
@@ -200,6 +202,37 @@ def test_gnn_forward_scaled_weights(dev, variant):
     np.testing.assert_allclose(logits.cpu().numpy(), ref["logits"], atol=2e-4, rtol=2e-4)
     np.testing.assert_allclose(vpre.cpu().numpy(), ref["value_pre"], atol=2e-4, rtol=2e-4)
     _lib.set_option("trunk_variant", 3)
+
+
+def test_gnn_fp16_range_guard(dev):
+    """The default kernels hold activations as fp16 hi + lo pairs: fp32-equivalent only inside fp16 range.  The reference's
+    fp32 has no such cliff (pv_network_gnn.py:53-64), so every weight set is checked against the exact f32 kernels on
+    calibration boards when it is packed: a sanely scaled net (also x3, with non-zero biases, as above) keeps the fast kernels,
+    weights x300 (activations ~1e9) are served by the exact ones -- and still match the fp64 oracle in relative terms."""
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay
+    from oracle import gnn as og
+    model, params = _model(3)
+    assert model.gnn_flags(dev) == 0
+    g = U.golden("walk_9x9.npz")
+    recs = g["states"][7000:7048]
+    for scale, want_flag in ((3.0, 0), (300.0, _lib.GNN_EXACT_F32)):
+        big = {k: (v * (scale if "gcn" in k and "weight" in k else 1.0)).astype(np.float32) for k, v in params.items()}
+        big["gcn_layers.0.bias"] = np.linspace(-0.2, 0.4, 128).astype(np.float32)
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in big.items()})
+        assert model.gnn_flags(dev) == want_flag, scale
+        ref = og.forward_states(big, recs)
+        _, _, logits, vpre = model.forward_states(torch.from_numpy(recs).to(dev), want_logits=True)
+        lg, vp = logits.cpu().numpy().astype(np.float64), vpre.cpu().numpy().astype(np.float64)
+        assert np.isfinite(lg).all() and np.isfinite(vp).all()
+        sc = np.abs(ref["logits"]).max()
+        np.testing.assert_allclose(lg, ref["logits"], atol=2e-5 * max(sc, 1.0), rtol=2e-4)
+        np.testing.assert_allclose(vp, ref["value_pre"], atol=2e-5 * max(np.abs(ref["value_pre"]).max(), 1.0), rtol=2e-4)
+    # the flag travels into the engine: a search with the x300 net uses the exact kernels and stays finite
+    eng = BatchedSelfPlay(model, num_games=4, sims=6, record_history=False)
+    assert eng.e.gnn_flags == _lib.GNN_EXACT_F32
+    visits, _, cnt = eng.search(recs[:4])
+    assert int(visits.sum()) == 4 * 5
 
 
 def test_gnn_small_boards_forward_and_selfplay(dev):
@@ -297,6 +330,49 @@ def test_predict_contract(dev):
     assert abs(val - ref["value"][0]) < 1e-5
 
 
+def _root_children(eng):
+    """Root children of every game after a search, straight from the tree pool (csrc/mcts.hip NodeRec, 32 bytes:
+    f64 w | f32 p | i32 n | u32 first_child + (count << 24) | u32 action | pad): (priors, visits, actions) per game."""
+    G, cap = eng.G, eng.node_cap
+    raw = eng.t["node_rec"].view(torch.uint8).view(G, cap, 32).cpu().numpy()
+    out = []
+    for g in range(G):
+        kids = int(raw[g, 0, 16:20].view(np.uint32)[0])
+        first, cnt = kids & 0xFFFFFF, kids >> 24
+        ch = raw[g, first:first + cnt]
+        out.append((ch[:, 8:12].copy().view(np.float32)[:, 0], ch[:, 12:16].copy().view(np.int32)[:, 0],
+                    ch[:, 20:24].copy().view(np.uint32)[:, 0]))
+    return out
+
+
+def test_engine_priors_and_visits_vs_oracle_gnn(dev):
+    """P0 INSIDE the engine (pv_network_cnn.py:129-132 as done by game_expand_backup with prior_mode 0: gather the softmax
+    output at legal_actions() in order, divide by the sum): the priors stored in the root's children must equal
+    OracleModel.predict (fp64 GNN + C rules) to 1e-6, child i must carry legal action i, and a 10-simulation search must
+    distribute its visits exactly like oracle.mcts driven by that model (pv_mcts.py:47-57)."""
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay
+    from oracle import gnn as og, mcts as om, quoridor as oq
+    model, params = _model(4)
+    oracle = og.OracleModel(params)
+    g = U.golden("walk_9x9.npz")
+    idx = [0, 5, 40, 333, 1200, 2600, 5000, 9000]
+    recs = np.stack([g["states"][i] for i in idx])
+    recs = recs[[not (oq.State(r).is_done()) for r in recs]]
+    sims = 10
+    eng = BatchedSelfPlay(model, num_games=recs.shape[0], sims=sims, record_history=False)
+    eng.search(recs)
+    torch.cuda.synchronize()
+    for rec, (pri, vis, act) in zip(recs, _root_children(eng)):
+        st = oq.State(rec)
+        legal = st.legal_actions()
+        assert [int(a) for a in act] == [int(a) for a in legal]
+        want, _ = oracle.predict(st)
+        np.testing.assert_allclose(pri, want, atol=1e-6, rtol=1e-5)
+        assert abs(float(pri.sum()) - 1.0) < 1e-5
+        root = om.search(oracle, st, sims)
+        assert [int(v) for v in vis] == [c.n for c in root.children]
+
+
 # ------------------------------------------------------------------ K4 MCTS / self-play against reference traces
 @pytest.mark.parametrize("N", [9, 5, 3])
 def test_mcts_visit_counts_match_reference_traces(dev, N):
@@ -354,6 +430,30 @@ def test_evaluation_games_match_reference(dev, N):
         assert plies == len(ref_actions)
         assert np.array_equal(eng.t["hist_action"][0, :plies].cpu().numpy().astype(np.int16), ref_actions)
         assert points == [float(g[f"e{i}_point"][0])]
+
+
+@pytest.mark.parametrize("cfg", [(0, 61), (1, 0), (1, 1), (1, 2), (1, 5)])
+def test_step_kernel_variants_bit_identical(dev, cfg):
+    """The simulation step exists in two forms (csrc/mcts.hip): `step_variant` 0 = expand / backup through memory, fence,
+    select; 1 (default) = one load round + the previous simulation's updates applied in registers to whatever the descent
+    loads.  Variant 1 hands over to memory once a path gets deeper than `step_fast_depth` (61 by default, i.e. never in
+    practice): with the limit at 0, 1, 2 and 5 every hand-over point is exercised.  All forms must reproduce the
+    reference's traces, self-play games and evaluation games bit for bit."""
+    from alphaquoridorgnn_amd import _lib
+    variant, depth = cfg
+    _lib.set_option("step_variant", variant)
+    _lib.set_option("step_fast_depth", depth)
+    try:
+        test_mcts_visit_counts_match_reference_traces(dev, 9)
+        test_selfplay_games_match_reference(dev, 9)
+        test_evaluation_games_match_reference(dev, 9)
+        test_mcts_visit_counts_match_reference_traces(dev, 5)
+        test_mcts_many_games_equal_single_game(dev)
+        if variant == 1 and depth == 2:
+            test_engine_priors_and_visits_vs_oracle_gnn(dev)
+    finally:
+        _lib.set_option("step_variant", 1)
+        _lib.set_option("step_fast_depth", 61)
 
 
 def test_batched_match_colours_and_points(dev):
@@ -438,6 +538,85 @@ def test_selfplay_generation_with_gnn(dev):
         else:
             assert zz[0] == 0
         off += p
+
+
+def test_selfplay_generation_full_config_invariants(dev):
+    """BASELINE configs[2] at its full size -- 2048 concurrent games x 200 simulations per move, GNN evaluator, the four
+    game sets the benchmark uses -- through the structural invariants of a generation: every game ends; every recorded
+    position's visits sit on legal actions only and sum to sims - 1;
+    consecutive states chain through next(); z alternates from the terminal result."""
+    from alphaquoridorgnn_amd.engine import MultiSetSelfPlay
+    from alphaquoridorgnn_amd import game_logic as gl
+    model, _ = _model(0)
+    G, sims = 2048, 200
+    eng = MultiSetSelfPlay(model, num_games=G, sims=sims, num_sets=4, seed=11)
+    c = eng.play_generation()
+    assert c["finished"] == G and c["active"] == 0 and c["dead_ends"] == 0
+    for e in eng.sets:
+        plies = e.t["game_plies"].cpu().numpy()
+        assert plies.min() >= 8 and plies.max() <= 116
+        st = e.t["hist_state72"]; vis = e.t["hist_visits"].to(torch.int32); act = e.t["hist_action"].long()
+        hp = st.shape[1]
+        valid = torch.arange(hp, device=dev).unsqueeze(0) < e.t["game_plies"].unsqueeze(1)
+        flat = st[valid]
+        mask, _, _ = gl.legal_actions_batch(flat.contiguous(), 9)
+        v = vis[valid]
+        assert int((v * (1 - mask.to(torch.int32))).abs().sum()) == 0              # visits only on legal actions
+        tot = v.sum(1)
+        assert int(tot.max()) == sims - 1 and int(tot.min()) == sims - 1            # every simulation after the first passes one root child
+        a = act[valid]
+        assert bool((mask.gather(1, a.unsqueeze(1)) == 1).all())                    # the chosen action is legal
+        nxt = gl.next_batch(flat.contiguous(), a.to(torch.int32), 9)
+        # state at ply p+1 of the same game == next(state at ply p, action at ply p)
+        has_next = valid.clone(); has_next[:, :-1] &= valid[:, 1:]; has_next[:, -1] = False
+        nn = torch.zeros_like(st); nn[valid] = nxt
+        assert torch.equal(nn[has_next], torch.roll(st, -1, 1)[has_next])
+    s72, visits, z = eng.history_tensors()
+    assert s72.shape[0] == int(sum(int(e.t["game_plies"].sum()) for e in eng.sets))
+    assert set(np.unique(z.cpu().numpy()).tolist()) <= {-1, 0, 1}
+
+
+def test_slot_refill_games_equal_standalone_games(dev):
+    """A rank plays a QUOTA of games on G slots (the reference's plain loop over games, self_play.py:81-84): a slot whose
+    game has ended takes the next game not yet handed out.  Every game played that way -- whichever slot, whenever it
+    started -- must be exactly the game a stand-alone one-game engine plays on the same per-game stream of uniforms
+    (its slot's column of the uniform matrix from its first move on): states, visit counts, actions and result."""
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay
+    G, Q, sims, bias = 6, 23, 12, 40
+    rs = np.random.RandomState(99)
+    U_all = torch.from_numpy(rs.random_sample((116 * 4, G)))
+    eng = BatchedSelfPlay(None, num_games=G, quota=Q, sims=sims, evaluator="fake", fake_bias=bias)
+    c = eng.play_generation(uniforms=U_all, check_every=1)
+    assert c["finished"] == Q and c["started"] == Q and c["active"] == 0 and c["dead_ends"] == 0
+    plies = eng.t["game_plies"].cpu().numpy(); slot = eng.t["game_slot"].cpu().numpy(); first = eng.t["game_first_move"].cpu().numpy()
+    done = eng.t["game_done"].cpu().numpy(); res = eng.t["game_result"].cpu().numpy()
+    assert done.all() and (slot >= 0).all() and sorted(slot[:G].tolist()) == list(range(G)) and (first[:G] == 0).all()
+    # a slot's games follow each other without a gap: game starts == previous game's first move + its plies
+    for g in range(G):
+        ks = [k for k in range(Q) if slot[k] == g]
+        assert all(first[b] == first[a] + plies[a] for a, b in zip(ks, ks[1:]))
+    # the slots never idled before the quota ran out: moves made == the longest slot's total
+    assert c["moves"] == max(sum(plies[k] for k in range(Q) if slot[k] == g) for g in range(G))
+    one = BatchedSelfPlay(None, num_games=1, sims=sims, evaluator="fake", fake_bias=bias)
+    hs, hv, ha = eng.t["hist_state72"].cpu().numpy(), eng.t["hist_visits"].cpu().numpy(), eng.t["hist_action"].cpu().numpy()
+    for k in range(Q):
+        one.reset()
+        one.play_generation(uniforms=U_all[first[k]:first[k] + 116, slot[k]:slot[k] + 1], check_every=1)
+        p = int(one.t["game_plies"][0])
+        assert p == plies[k], k
+        assert np.array_equal(one.t["hist_state72"][0, :p].cpu().numpy(), hs[k, :p]), k
+        assert np.array_equal(one.t["hist_visits"][0, :p].cpu().numpy(), hv[k, :p]), k
+        assert np.array_equal(one.t["hist_action"][0, :p].cpu().numpy(), ha[k, :p]), k
+        assert int(one.t["game_result"][0]) == res[k], k
+    st, vis, z = eng.history_tensors()
+    assert st.shape[0] == plies.sum()
+    # the same through several game sets with the GNN evaluator: every set fills its own quota
+    from alphaquoridorgnn_amd.engine import MultiSetSelfPlay
+    model, _ = _model(0)
+    ms = MultiSetSelfPlay(model, num_games=8, quota=20, sims=6, num_sets=2, seed=3)
+    c = ms.play_generation()
+    assert c["finished"] == 20 and c["active"] == 0
+    assert ms.history_tensors()[0].shape[0] == sum(int(e.t["game_plies"].sum()) for e in ms.sets)
 
 
 def test_multiset_selfplay_equals_standalone_sets(dev):
@@ -647,6 +826,208 @@ def test_train_cycle_on_5x5_board(dev, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "PROMOTED [" in r.stdout
     assert (tmp_path / "models" / "GNN" / "5x5" / "latest.pth").exists() and len(list((tmp_path / "data").glob("*.history"))) == 1
+
+
+def test_self_play_generations_differ_unless_seeded(dev, tmp_path, monkeypatch):
+    """The reference samples from the unseeded global numpy RNG (self_play.py:57): two generations with unchanged weights
+    never repeat.  Same here -- and a fixed seed (argument or AQG_SELFPLAY_SEED) reproduces a generation exactly."""
+    import pickle
+    from alphaquoridorgnn_amd import self_play as sp, pv_mcts
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(pv_mcts, "PV_EVALUATE_COUNT", 8)
+    monkeypatch.setattr(sp, "write_data", lambda h: h)                  # keep the rows, skip the one-file-per-second naming
+    model, _ = _model(1)
+    a = sp.self_play(model, games=6)
+    b = sp.self_play(model, games=6)
+    assert a != b, "two unseeded generations replayed the same uniform stream"
+    c = sp.self_play(model, games=6, seed=77)
+    d = sp.self_play(model, games=6, seed=77)
+    assert c == d
+    monkeypatch.setenv("AQG_SELFPLAY_SEED", "77")
+    assert sp.self_play(model, games=6) == c
+
+
+_SHARD_WORKER = r"""
+import os, sys, pickle
+sys.path.insert(0, os.environ["AQG_REPO"])
+import numpy as np, torch, torch.distributed as dist
+from alphaquoridorgnn_amd import self_play as sp, pv_mcts, train_cycle as tc, train_network as tn, evaluate_network as en
+from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+from oracle import gnn as og
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["AQG_PORT"], rank=rank, world_size=2)
+os.chdir(os.environ["AQG_CWD"])
+pv_mcts.PV_EVALUATE_COUNT = 8
+if os.environ["AQG_MODE"] == "selfplay":
+    m = GNNNetwork(); m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in og.init_params(2).items()}); m = m.to("cuda").eval()
+    sp.self_play(m, games=7, seed=500)                       # rank 0: 4 games, rank 1: 3 games
+else:
+    sp.SP_GAME_COUNT = 6; tn.NUM_EPOCH = 2; en.EN_GAME_COUNT = 4
+    out = tc.train_cycle(num_cycles=2)
+    sd = torch.load(os.path.join("models", "GNN", "9x9", "latest.pth"), map_location="cpu", weights_only=True)
+    with open(f"cycle.{rank}.pkl", "wb") as f:
+        pickle.dump((out, {k: v.numpy() for k, v in sd.items()}), f)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def _run_two_ranks(tmp_path, mode):
+    import subprocess
+    (tmp_path / "worker.py").write_text(_SHARD_WORKER)
+    env = dict(os.environ, AQG_REPO=REPO, AQG_PORT=str(29900 + os.getpid() % 90), AQG_CWD=str(tmp_path), AQG_MODE=mode)
+    procs = [subprocess.Popen([sys.executable, str(tmp_path / "worker.py")], env=dict(env, RANK=str(r))) for r in range(2)]
+    assert all(p.wait(timeout=900) == 0 for p in procs)
+
+
+def test_sharded_self_play_two_ranks_equals_standalone_engines(dev, tmp_path):
+    """BASELINE configs[3] on two ranks (gloo, both on this one GPU -- RCCL needs a GPU per rank; the host code path is the
+    same): self_play(games=7) shards 4 + 3, the ranks exchange their (s, pi, z) rows once, rank 0 writes ONE history file.
+    That file must be the concatenation, in rank order, of what two stand-alone engines with the ranks' seeds produce."""
+    import pickle
+    from alphaquoridorgnn_amd.engine import MultiSetSelfPlay
+    from alphaquoridorgnn_amd import self_play as sp
+    _run_two_ranks(tmp_path, "selfplay")
+    files = sorted((tmp_path / "data").glob("*.history"))
+    assert len(files) == 1
+    with open(files[0], "rb") as f:
+        rows = pickle.load(f)
+    model, _ = _model(2)
+    want = []
+    for rank, games in ((0, 4), (1, 3)):
+        eng = MultiSetSelfPlay(model, num_games=games, sims=8, num_sets=1, seed=500 + rank)
+        eng.play_generation()
+        want += sp._history_rows(*eng.history_tensors(), 9)
+    assert len(rows) == len(want) and rows == want
+
+
+def test_train_cycle_two_ranks(dev, tmp_path):
+    """Two whole cycles under torch.distributed (2 ranks, gloo): sharded self-play, data-parallel training on the file
+    rank 0 wrote (nobody reads it early), evaluation by rank 0 with the decision broadcast.  Both ranks must agree on the
+    promotions and hold identical weights; every cycle leaves one history file."""
+    import pickle
+    _run_two_ranks(tmp_path, "cycle")
+    outs = []
+    for r in range(2):
+        with open(tmp_path / f"cycle.{r}.pkl", "rb") as f:
+            outs.append(pickle.load(f))
+    assert outs[0][0] == outs[1][0] and len(outs[0][0]) == 2
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+    # one history file per generation, named by the second like the reference's (self_play.py:33-35): two of these tiny
+    # generations can share a name
+    assert 1 <= len(list((tmp_path / "data").glob("*.history"))) <= 2
+
+
+# ------------------------------------------------------------------ external evaluator (any BaseNetwork-style model)
+class _OracleFakeAdapter:
+    """oracle.mcts.FakeModel behind the reference's predict(state, device) contract, fed with OUR game_logic.State."""
+
+    def __init__(self, bias):
+        from oracle import mcts as om
+        self.m = om.FakeModel(bias)
+
+    def predict(self, state, device=None):
+        from oracle import quoridor as oq
+        return self.m.predict(oq.State(state.record()))
+
+
+def test_external_evaluator_reproduces_reference_traces(dev):
+    """prior_mode 2: the engine selects / expands / backs up, the CALLER's model.predict (BaseNetwork.py:36-40, called once
+    per simulation like pv_mcts.py:47) supplies priors and value from the host.  Driven by the integer-hash model it must
+    give the reference's visit distributions bit for bit, like the in-kernel fake evaluator does."""
+    from alphaquoridorgnn_amd.pv_mcts import pv_mcts_policy_batch
+    g = U.golden("mcts_9x9.npz")
+    n = int(g["count"][0])
+    done = 0
+    for k in range(n):
+        sims, bias, T = g[f"t{k}_cfg"]
+        if int(sims) != 50 or done >= 6:
+            continue
+        pol = pv_mcts_policy_batch(_OracleFakeAdapter(int(bias)), g[f"t{k}_state"][None], float(T), sims=50, board_size=9,
+                                   evaluator="external")[0]
+        assert np.array_equal(np.asarray(pol, dtype=np.float64), g[f"t{k}_policy"]), k
+        done += 1
+    assert done == 6
+    # a whole reference game (self_play.play) through the external path: same states, policies and z
+    gg = U.golden("games_9x9.npz")
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay
+    seed, sims, bias = (int(x) for x in gg["g2_cfg"])
+    rs = np.random.RandomState(seed)
+    eng = BatchedSelfPlay(_OracleFakeAdapter(bias), num_games=1, sims=sims, evaluator="external")
+    uni = torch.from_numpy(rs.random_sample(116).reshape(116, 1))
+    eng.play_generation(uniforms=uni, check_every=1)
+    h = eng.history()
+    assert len(h) == gg["g2_states"].shape[0]
+    for i, (sa, pol, z) in enumerate(h):
+        assert np.array_equal(np.asarray(pol), gg["g2_policy"][i]) and z == int(gg["g2_z"][i])
+        assert sa[0] == [int(x) for x in gg["g2_states"][i, 0:2]] and sa[2] == [int(x) for x in gg["g2_states"][i, 4:68]]
+
+
+class _StockCNN(torch.nn.Module):
+    """A stock-PyTorch policy-value CNN of the shape the reference wires (pv_network_cnn.py:50-86: 3x3 conv + BN stem, 16
+    residual blocks of 128 filters, global average pool, Linear->Softmax policy over 209 actions, Linear->Tanh value) with
+    the BaseNetwork contract (name / predict / preprocess_input).  Own code, random weights, CPU: plumbing only."""
+
+    def __init__(self, filters=128, blocks=16, board=9):
+        super().__init__()
+        nn = torch.nn
+        self.board, self.actions = board, board * board + 2 * (board - 1) ** 2
+
+        def unit(cin):
+            return nn.Sequential(nn.Conv2d(cin, filters, 3, padding=1, bias=False), nn.BatchNorm2d(filters))
+        self.stem = unit(6)
+        self.tower = nn.ModuleList([nn.ModuleList([unit(filters), unit(filters)]) for _ in range(blocks)])
+        self.policy = nn.Linear(filters, self.actions)
+        self.value = nn.Linear(filters, 1)
+        self.name = "CNN"
+
+    def forward(self, x):
+        x = torch.relu(self.stem(x))
+        for a, b in self.tower:
+            x = torch.relu(b(torch.relu(a(x))) + x)
+        x = x.mean(dim=(2, 3))
+        return torch.softmax(self.policy(x), dim=1), torch.tanh(self.value(x))
+
+    def preprocess_input(self, arrays):
+        N = self.board
+        out = np.zeros((len(arrays), 6, N, N), dtype=np.float32)
+        for i, (player, enemy, walls) in enumerate(arrays):
+            out[i, 0].flat[player[0]] = 1; out[i, 1] = player[1]
+            out[i, 2].flat[enemy[0]] = 1; out[i, 3] = enemy[1]
+            for slot, w in enumerate(walls):
+                if w:
+                    out[i, 3 + w, slot // (N - 1), slot % (N - 1)] = 1
+        return out
+
+    def predict(self, state, device="cpu"):
+        x = torch.from_numpy(self.preprocess_input([state.to_array()]))
+        with torch.inference_mode():
+            p, v = self(x)
+        p = p[0][list(state.legal_actions())]
+        p = p / (p.sum() if p.sum() else 1)
+        return p.numpy(), float(v.item())
+
+
+def test_play_with_stock_cnn_is_plumbing_compatible(dev, monkeypatch):
+    """BASELINE configs[0]: one self_play.play() game with a CNN of the reference's shape on the CPU.  The model is NOT ours
+    (no packed_weights): pv_mcts / self_play must accept anything with the reference's predict() and run the search on the
+    engine with the model as external evaluator."""
+    from alphaquoridorgnn_amd import pv_mcts, self_play
+    from alphaquoridorgnn_amd.game_logic import State
+    torch.manual_seed(0)
+    model = _StockCNN().eval()
+    assert sum(p.numel() for p in model.parameters()) > 4_000_000            # the 4.76 M-parameter tower of the reference
+    monkeypatch.setattr(pv_mcts, "PV_EVALUATE_COUNT", 4)
+    s = State()
+    pol = pv_mcts.pv_mcts_policy(model, s, 1.0, "cpu")
+    assert len(pol) == len(s.legal_actions()) == 131 and abs(sum(pol) - 1.0) < 1e-9
+    a = pv_mcts.pv_mcts_action(model, 1.0, "cpu")(s)
+    assert a in s.legal_actions()
+    hist = self_play.play(model, "cpu")
+    assert 8 <= len(hist) <= 116 and len(hist[0][1]) == 209 and hist[0][0] == State().to_array()
+    zs = [h[2] for h in hist]
+    assert all(zs[i + 1] == -zs[i] for i in range(len(zs) - 1)) and zs[0] in (-1, 0, 1)
 
 
 # ------------------------------------------------------------------ drop-in surface (reference-shaped calls)

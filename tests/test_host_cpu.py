@@ -28,7 +28,7 @@ def test_capi_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} not bound in _lib.SIGNATURES"
     assert lib.aqg_abi_version() == _lib.ABI_VERSION
     assert lib.aqg_gcn_packed_floats(9) > 64082          # all 64,082 parameters + padding + fragment copies
-    assert ctypes.sizeof(_lib.EngineStruct) == 9 * 4 + 2 * 4 + 4 + 23 * 8   # 11 scalars (+4 pad) + 23 pointers
+    assert ctypes.sizeof(_lib.EngineStruct) == 11 * 4 + 2 * 4 + 4 + 27 * 8   # 13 scalars (+4 pad) + 27 pointers
     assert ctypes.sizeof(_lib.TrainStruct) == 8 * 4 + 4 * 14 * 8 + 20 * 8      # aqg_train: 8 scalars, 4 x 14 + 20 pointers
 
 
@@ -109,16 +109,18 @@ def test_weight_packing_layout():
     WH1 = WH2 + 2 * 2 * 128 * 128 // 2
     WHH1 = WH1 + 4 * 2 * 64 * 4
     WHP2 = WHH1 + 2 * 8 * 4 * 64 * 4
-    assert n == WHP2 + 2 * 14 * 2 * 64 * 4
+    TB = WHP2 + 2 * 14 * 2 * 64 * 4
+    assert n == TB + 3 * 5 * 128
+    CQ = 15.0 / 16.0                                                       # scale of the default trunk's activation image
     wf2 = out[WF2:WF2 + 128 * 128].reshape(4, 2, 8, 64, 4)                 # [wave][ntile][s4][lane][i]
     for (w, j, s4, lane, i) in [(0, 0, 0, 0, 0), (3, 1, 7, 63, 3), (2, 0, 5, 17, 2), (1, 1, 2, 40, 1)]:
         c, q = lane & 15, lane >> 4
         k = (q & 1) * 64 + (q >> 1) * 32 + 4 * s4 + i
         assert wf2[w, j, s4, lane, i] == p["gcn_layers.1.lin.weight"][32 * w + 16 * j + c, k]
-    # fp16 2-way split fragments (default trunk): hi = RNE_f16(w), lo = RNE_f16(w - hi)
+    # fp16 2-way split fragments (default trunk) of W / CQ: hi = RNE_f16(w), lo = RNE_f16(w - hi)
     for L, key in ((0, "gcn_layers.1.lin.weight"), (1, "gcn_layers.2.lin.weight")):
         wh = out[WH2 + L * 128 * 128:WH2 + (L + 1) * 128 * 128].view(np.uint16).reshape(2, 4, 2, 4, 64, 8)   # [plane][wave][ntile][kb][lane][8 halves]
-        W = p[key].astype(np.float32)
+        W = (p[key].astype(np.float64) / CQ).astype(np.float32)
         hi = W.astype(np.float16)
         lo = (W - hi.astype(np.float32)).astype(np.float16)
         wv, j, kb, lane, e = np.meshgrid(np.arange(4), np.arange(2), np.arange(4), np.arange(64), np.arange(8), indexing="ij")
@@ -134,6 +136,20 @@ def test_weight_packing_layout():
     cols = (32 * np.arange(4)[:, None, None] + 16 * np.arange(2)[None, :, None] + np.arange(16)[None, None, :])   # [wave][ntile][c]
     assert np.array_equal(w1[:, :, 0, :, :6], hi[cols].view(np.uint16)) and np.array_equal(w1[:, :, 1, :, :6], lo[cols].view(np.uint16))
     assert not w1[:, :, :2, :, 6:].any() and not w1[:, :, 2:].any()
+    # bias tables of the default trunk: TB[layer][deg - 1][f] = CQ * b[f] * sqrt(deg)   (random-init biases are zero: use a second set)
+    p2 = {k: v.copy() for k, v in p.items()}
+    rng = np.random.RandomState(3)
+    for L in range(3):
+        p2[f"gcn_layers.{L}.bias"] = rng.randn(128).astype(np.float32)
+    host2 = [np.ascontiguousarray(p2[k], dtype=np.float32) for k in og.KEYS]
+    arr2 = (ctypes.c_void_p * 14)(*[h.ctypes.data_as(ctypes.c_void_p) for h in host2])
+    out2 = np.zeros(n, dtype=np.float32)
+    assert lib.aqg_gcn_pack_weights_host(9, arr2, out2.ctypes.data_as(ctypes.c_void_p)) == 0
+    tb = out2[TB:TB + 3 * 5 * 128].reshape(3, 5, 128)
+    for L in range(3):
+        for deg in range(1, 6):
+            want = (CQ * p2[f"gcn_layers.{L}.bias"].astype(np.float64) * np.sqrt(float(deg))).astype(np.float32)
+            assert np.array_equal(tb[L, deg - 1], want)
     # heads: hidden layer A fragments [plane][unit tile][kb][q][c][8 halves], policy B fragments in accumulator k order
     hw = out[WHH1:WHP2].view(np.uint16).reshape(2, 8, 4, 4, 16, 8)
     Wh = np.concatenate([p["policy_head.0.weight"], p["value_head.0.weight"]], 0).astype(np.float32)      # [128 units, 128]
@@ -141,7 +157,7 @@ def test_weight_packing_layout():
     ut, kb, q, c, e = np.meshgrid(np.arange(8), np.arange(4), np.arange(4), np.arange(16), np.arange(8), indexing="ij")
     assert np.array_equal(hw[0], hi[16 * ut + c, 32 * kb + 8 * q + e].view(np.uint16))
     assert np.array_equal(hw[1], lo[16 * ut + c, 32 * kb + 8 * q + e].view(np.uint16))
-    pw = out[WHP2:n].view(np.uint16).reshape(2, 14, 2, 4, 16, 8)
+    pw = out[WHP2:TB].view(np.uint16).reshape(2, 14, 2, 4, 16, 8)
     Wp = np.zeros((224, 64), np.float32); Wp[:209] = p["policy_head.2.weight"]
     hi = Wp.astype(np.float16); lo = (Wp - hi.astype(np.float32)).astype(np.float16)
     at, kb, q, c, e = np.meshgrid(np.arange(14), np.arange(2), np.arange(4), np.arange(16), np.arange(8), indexing="ij")
@@ -195,3 +211,50 @@ def test_self_play_sharding_arithmetic():
         for world in (1, 2, 3, 8):
             mine = [total // world + (1 if r < total % world else 0) for r in range(world)]
             assert sum(mine) == total and max(mine) - min(mine) <= 1
+
+
+def test_history_file_format_interoperates_with_reference(tmp_path, monkeypatch):
+    """SURVEY 8 f2.  tests/golden/history_9x9.json is what the REFERENCE's self_play.write_data() pickled for one seeded game
+    of its own play() and what its load_data() read back (tools/gen_golden_history.py).  Our writer side (_history_rows: the
+    rows self_play() hands to write_data) must produce that list field for field from the engine's tensors, and our reader
+    side (train_network.load_data + the unzip of train_network.py:37-46) must turn a file with the reference's content into
+    the same training arrays."""
+    import json
+    import pickle
+    from alphaquoridorgnn_amd import self_play as sp, train_network as tn
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+    with open(os.path.join(U.GOLDEN, "history_9x9.json")) as f:
+        doc = json.load(f)
+    hist = doc["history"]
+    g = U.golden("games_9x9.npz")
+    st, pol, z = g["g2_states"], g["g2_policy"], g["g2_z"]           # the same reference game (seed 77, 24 sims, bias 60)
+    assert len(hist) == st.shape[0] == 27
+    for i, (s, p, v) in enumerate(hist):
+        assert s == [[int(st[i, 0]), int(st[i, 1])], [int(st[i, 2]), int(st[i, 3])], [int(x) for x in st[i, 4:68]]]
+        assert p == pol[i].tolist() and v == int(z[i])
+        assert len(p) == 209 and abs(sum(p) - 1.0) < 1e-12
+    # writer: engine tensors (state72 rows, dense root visit counts, z) -> rows; visit counts = policy * (sims - 1)
+    visits = np.rint(pol * 23).astype(np.int16)
+    assert np.array_equal(visits.sum(1), np.full(27, 23))
+    rows = sp._history_rows(torch.from_numpy(st), torch.from_numpy(visits), torch.from_numpy(z), 9)
+    assert rows == hist                                               # ints, float64 quotients and z all equal
+    assert all(type(x) is int for r in rows for part in r[0] for x in part) and all(type(r[2]) is int for r in rows)
+    # reader: a file with the reference's content (numpy.int64 pawn positions included, as in its pickles)
+    ref_like = [[[[np.int64(s[0][0]), s[0][1]], [np.int64(s[1][0]), s[1][1]], list(s[2])], list(p), v] for s, p, v in hist]
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("data")
+    with open(os.path.join("data", doc["file_name_pattern"]), "wb") as f:
+        pickle.dump(ref_like, f)
+    with open(os.path.join("data", "20000101000000.history"), "wb") as f:      # an older generation: must be ignored (:21)
+        pickle.dump(ref_like[:3], f)
+    back = tn.load_data()
+    assert len(back) == 27
+    s, p, v = zip(*back)                                                        # train_network.py:37
+    recs = GNNNetwork().preprocess_input(s)
+    want = st.copy(); want[:, 68:70] = 0                                        # plies are not part of to_array()
+    assert np.array_equal(recs, want)
+    assert list(np.array(p).shape) == doc["train_p_shape"] and np.array_equal(np.array(p), pol)
+    assert np.array(v).tolist() == doc["train_v"]
+    # the six feature planes the reference's featuriser builds from those states sum to the recorded checksum
+    from oracle import gnn as og
+    assert abs(sum(float(og.node_features(r).sum()) for r in want) - doc["train_planes_sum"]) < 1e-9

@@ -35,13 +35,13 @@ def child(variant):
     for _ in range(40):
         pooled = torch.full((B, 128), float("nan"), device=dev)
         _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None,
-                                              _lib.stream_ptr(dev)), "trunk")
+                                              0, _lib.stream_ptr(dev)), "trunk")
         outs.append(pooled)
     torch.cuda.synchronize()
     bad = [i for i, o in enumerate(outs) if not torch.equal(o, outs[-1])]
     _lib.set_option("trunk_variant", 0)
     ref = torch.empty((B, 128), device=dev)
-    _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(ref), None, None, None, None, _lib.stream_ptr(dev)), "trunk")
+    _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(ref), None, None, None, None, 0, _lib.stream_ptr(dev)), "trunk")
     err = float((outs[0] - ref).abs().max())
     print(f"variant {variant}: launches differing from the last: {bad[:8]} ({len(bad)}/40); first launch vs exact-f32 kernel max|d pooled| = {err:.3e}")
     return 1 if bad or not err < 1e-5 else 0

@@ -12,9 +12,9 @@ model = GNNNetwork().to(dev).eval(); pk = model.packed_weights(dev)
 for B in (256, 512, 1024, 2048, 8192):
     st = synth_states(B); pooled = torch.empty((B, 128), device=dev); pol = torch.empty((B, 209), device=dev); val = torch.empty((B,), device=dev)
     def trunk():
-        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, _lib.stream_ptr(dev)), "t")
+        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, 0, _lib.stream_ptr(dev)), "t")
     def full():
-        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(pol), None, _lib.ptr(val), _lib.stream_ptr(dev)), "t")
+        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(pol), None, _lib.ptr(val), 0, _lib.stream_ptr(dev)), "t")
     res = []
     for f in (trunk, full):
         for _ in range(10): f()

@@ -78,11 +78,11 @@ def main():
 
             def trunk():
                 _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None,
-                                                      _lib.stream_ptr(dev)), "trunk")
+                                                      0, _lib.stream_ptr(dev)), "trunk")
 
             def full():
                 _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy),
-                                                      None, _lib.ptr(value), _lib.stream_ptr(dev)), "full")
+                                                      None, _lib.ptr(value), 0, _lib.stream_ptr(dev)), "full")
             for rnd in range(2):
                 for v in (1, 6, 4):
                     _lib.set_option("trunk_variant", v)

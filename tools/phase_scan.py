@@ -15,7 +15,7 @@ _lib.set_option("trunk_delay_min_boards", 0)
 for B in (256, 512, 1024, 2048, 4096, 16384, 65536):
     st = synth_states(B); pooled = torch.empty((B, 128), device=dev)
     def run():
-        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, _lib.stream_ptr(dev)), "t")
+        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, 0, _lib.stream_ptr(dev)), "t")
     for delay in (0, 100):
         _lib.set_option("trunk_phase_delay", delay)
         for _ in range(5): run()

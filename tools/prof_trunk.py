@@ -22,6 +22,6 @@ policy = torch.empty((B, 209), device=dev)
 value = torch.empty((B,), device=dev)
 for _ in range(iters):
     _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None,
-                                          _lib.ptr(value), _lib.stream_ptr(dev)), "fwd")
+                                          _lib.ptr(value), 0, _lib.stream_ptr(dev)), "fwd")
 torch.cuda.synchronize()
 print("done", B, variant)

@@ -23,7 +23,7 @@ for v, grid in ((3, 256), (3, 512), (4, 512)):
     _lib.set_option("trunk_variant", v); _lib.set_option("trunk_grid", grid)
     pooled = torch.zeros((B + 1, 128), device=dev)
     for _ in range(3):
-        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, _lib.stream_ptr(dev)), "t")
+        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, 0, _lib.stream_ptr(dev)), "t")
     torch.cuda.synchronize()
     raw = pooled[B].view(torch.int64)[:17].cpu().tolist()
     n = raw[16]; tot = sum(raw[:16])
