@@ -11,4 +11,4 @@ import os as _os
 # has to be in the environment before the first GPU call; an explicit setting by the user wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-__all__ = ["constants", "game_logic", "pv_network_gnn", "pv_mcts", "self_play", "evaluate_network", "train_network", "train_cycle", "engine"]
+__all__ = ["constants", "game_logic", "pv_network_gnn", "pv_mcts", "self_play", "evaluate_network", "train_network", "train_cycle", "engine", "agents"]

@@ -70,6 +70,11 @@ SIGNATURES = {
     "aqg_engine_set_roots": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp]),
     "aqg_engine_root_visits": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp, _vp, _vp]),
     "aqg_gcn_train_step": (_c.c_int, [_c.POINTER(TrainStruct), _vp, _vp, _vp, _c.c_int, _vp]),
+    "aqg_host_legal_actions": (_c.c_int, [_c.c_int, _vp, _vp]),
+    "aqg_host_next": (_c.c_int, [_c.c_int, _vp, _c.c_int, _vp]),
+    "aqg_host_shortest_path": (_c.c_int, [_c.c_int, _vp]),
+    "aqg_host_heuristic_eval": (_c.c_double, [_c.c_int, _vp, _c.c_int]),
+    "aqg_host_alpha_beta_action": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _c.c_int]),
 }
 
 _lib = None

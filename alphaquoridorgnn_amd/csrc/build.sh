@@ -11,6 +11,9 @@ for f in legal_mask gcn_forward gcn_train mcts capi; do
   $HIPCC $FLAGS -c $f.hip -o ${OBJDIR}/aqg_$f.o &
   objs+=(${OBJDIR}/aqg_$f.o)
 done
+# host-only code (CPU baseline agents over the same rule header): plain C++, no device pass
+${CXX:-g++} -O2 -std=c++17 -fPIC -Wall -Wno-unknown-pragmas -c host_agents.cpp -o ${OBJDIR}/aqg_host_agents.o &
+objs+=(${OBJDIR}/aqg_host_agents.o)
 wait
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT "${objs[@]}" -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib
 echo "built $(realpath $OUT)"

@@ -10,6 +10,7 @@ extern int g_trunk_grid;
 extern int g_trunk_phase_delay;
 extern int g_trunk_delay_min_boards;
 extern int g_use_graph;
+extern int g_fuse_heads;
 extern int g_step_variant;
 extern int g_step_fast_depth;
 int profile_collect(double* total_ms, long long* launches, long long* boards, int reset);
@@ -57,6 +58,7 @@ int aqg_set_option(const char* name, int value) {
     if (name && !strcmp(name, "trunk_delay_min_boards")) { g_trunk_delay_min_boards = value; return 0; }
     if (name && !strcmp(name, "step_variant")) { g_step_variant = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "step_fast_depth")) { if (value < 0 || value > 61) return fail("step_fast_depth must be 0..61"); g_step_fast_depth = value; return 0; }
+    if (name && !strcmp(name, "fuse_heads")) { g_fuse_heads = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "use_graph")) { g_use_graph = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "profile_trunk")) { g_profile_trunk = value ? 1 : 0; return 0; }
     return fail("unknown option", name ? name : "(null)");

@@ -777,7 +777,7 @@ __device__ __forceinline__ void request_bias(f32x4 (&out)[6][JT], __amdgpu_buffe
 // (No plane byte is read here: the caller has passed the barrier behind the linear map, the stores are free to go.)
 template <int JT, bool LAST>
 __device__ __forceinline__ void aggregate_store(TrunkSmemM<8 / JT>& sm, u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], f32x4 (&out)[6][JT], int wave, int lane,
-                                                __amdgpu_buffer_rsrc_t pooled_rs, int pooled_soff) {
+                                                __amdgpu_buffer_rsrc_t pooled_rs, int pooled_soff, float* pooled_lds = nullptr) {
     constexpr int AHEAD = 3;                                   // adjacency fragments in flight (4 registers each)
     const int c = lane & 15, q = lane >> 4;
     const int col0 = 16 * JT * wave + 4 * q;
@@ -836,6 +836,7 @@ __device__ __forceinline__ void aggregate_store(TrunkSmemM<8 / JT>& sm, u32x4 (&
             for (int e = 0; e < 4; ++e) t[e] = row16_sum(sum[j][e]) * (float)(1.0 / (81.0 * CQ));
             // (buffer store off an SGPR descriptor + scalar row offset: no 64-bit address registers alive across the board loop)
             if (c == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), pooled_rs, (col0 + 16 * j) * 4, pooled_soff, 0);
+            if (pooled_lds && c == 0) *reinterpret_cast<f32x4*>(pooled_lds + col0 + 16 * j) = t;
         }
     }
 }
@@ -845,12 +846,134 @@ __device__ __forceinline__ uint32_t bit_of64(uint64_t m, int s) {             //
     return (w >> (s & 31)) & 1u;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Heads of ONE board by the workgroup that has just pooled it (8-wave form, launches of at most FUSE_HEADS_MAX boards -- the
+// MCTS's): policy MLP 128 -> 64 -> A (+ Softmax), value MLP 128 -> 64 -> 1 (+ Tanh), pv_network_gnn.py:38-51,:62-63, in exact
+// f32 on the vector unit.  One board is a matrix-vector product: nothing for the matrix pipe, but 128 KB of weights from L2
+// per board -- affordable for a few hundred boards per launch (a separate launch of the 16-boards-per-workgroup MFMA heads
+// costs 6.4 us + a kernel boundary per simulation there), not for 65,536.  `scr` = 5 KB of LDS (the plane image is dead).
+//   phase 1  hidden unit u = tid & 127 over k quarter tid >> 7 (32 coalesced weight loads in flight per thread)
+//   phase 2  action a = tid & 255 over hidden half tid >> 8;  wave 7 also reduces the value head
+//   phase 3  softmax over the A logits: DPP maxima / sums per wave, combined through LDS
+// ---------------------------------------------------------------------------------------------
+constexpr int FUSE_HEADS_MAX = 1024;
+struct alignas(16) FusedHeadsScratch {
+    alignas(16) float g[HID];            // pooled features of the board
+    alignas(16) float part[4][HID];      // hidden-layer partial sums of the four k quarters
+    alignas(16) float hid[HID];          // hidden activations: 0..63 policy head, 64..127 value head
+    alignas(16) float lpart[2][APAD];    // logit partial sums of the two hidden halves
+    float red[2][8];                     // per-wave softmax maxima / sums
+};
+static_assert(sizeof(FusedHeadsScratch) <= PPLANE, "fused heads scratch lives in the (dead) hi plane");
+
+__device__ __forceinline__ float wave_max_all(float x) {       // maximum of the 64 lanes, in every lane
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false)));
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false)));
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false)));
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false)));
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false)));
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, false)));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+__device__ __forceinline__ float wave_sum_all(float x) {       // fixed-order sum of the 64 lanes, in every lane
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
+// All 512 threads of the workgroup call this between two barriers of their own; on return the board's outputs are stored.
+__device__ __forceinline__ void fused_heads_512(FusedHeadsScratch& sc, __amdgpu_buffer_rsrc_t rs, const float* __restrict__ pk, int A, int tid,
+                                                float* __restrict__ logits_row, float* __restrict__ policy_row,
+                                                float* __restrict__ value_pre, float* __restrict__ value) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (weights by buffer loads off the packed buffer's SGPR descriptor: lane offset + scalar row offset.  With plain pointers
+    //  the compiler precomputes all 64 row addresses per thread outside the board loop -- and spills them.)
+    {   // phase 1
+        const int u = tid & 127, kq = wave >> 1;
+        const int base = (int)(PackedLayout::HW1T * sizeof(float)) + (32 * kq) * (HID * 4);
+        float acc = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                 // two batches of 16 loads in flight
+            float wk[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wk[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, u * 4, base + (16 * h + j) * (HID * 4), 0));
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(&sc.g[32 * kq + 16 * h + 4 * j4]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = fmaf(gv[i], wk[4 * j4 + i], acc);
+            }
+        }
+        sc.part[kq][u] = acc;
+    }
+    __syncthreads();
+    if (tid < HID) sc.hid[tid] = fmaxf(((sc.part[0][tid] + sc.part[1][tid]) + (sc.part[2][tid] + sc.part[3][tid])) + pk[PackedLayout::HB1 + tid], 0.f);
+    __syncthreads();
+    {   // phase 2
+        const int a = tid & 255, uh = wave >> 2;
+        const int base = (int)(PackedLayout::PW2T * sizeof(float)) + (32 * uh) * (APAD * 4);
+        float acc = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float wk[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wk[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, a * 4, base + (16 * h + j) * (APAD * 4), 0));
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(&sc.hid[32 * uh + 16 * h + 4 * j4]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = fmaf(hv[i], wk[4 * j4 + i], acc);
+            }
+        }
+        sc.lpart[uh][a] = acc;
+        if (wave == 7) {     // value head: 64 hidden units, one per lane
+            const float v = wave_sum_all(sc.hid[HID / 2 + lane] * pk[PackedLayout::VW2 + lane]) + pk[PackedLayout::VB2];
+            if (lane == 0) {
+                if (value_pre) *value_pre = v;
+                if (value) *value = tanhf(v);
+            }
+        }
+    }
+    __syncthreads();
+    if (!logits_row && !policy_row) return;
+    // phase 3: waves 0..3 hold the logits (a = tid < 256), softmax over a < A
+    float lg = -INFINITY;
+    if (tid < APAD) {
+        if (tid < A) lg = (sc.lpart[0][tid] + sc.lpart[1][tid]) + pk[PackedLayout::PB2 + tid];
+        const float m = wave_max_all(lg);
+        if (lane == 0) sc.red[0][wave] = m;
+    }
+    __syncthreads();
+    float ex = 0.f, M = 0.f;
+    if (tid < APAD) {
+        M = fmaxf(fmaxf(sc.red[0][0], sc.red[0][1]), fmaxf(sc.red[0][2], sc.red[0][3]));
+        ex = tid < A ? expf(lg - M) : 0.f;
+        const float ssum = wave_sum_all(ex);
+        if (lane == 0) sc.red[1][wave] = ssum;
+    }
+    __syncthreads();
+    if (tid < A) {
+        const float S = (sc.red[1][0] + sc.red[1][1]) + (sc.red[1][2] + sc.red[1][3]);
+        if (logits_row) logits_row[tid] = lg;
+        if (policy_row) policy_row[tid] = ex / S;
+    }
+}
+
 // (hipcc's second launch-bound argument is waves per SIMD: workgroups per CU x waves per workgroup / 4 SIMDs)
-template <int JT, int WGS_PER_CU>
+template <int JT, int WGS_PER_CU, bool FUSE = false>
 __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trunk_boards_mm_kernel(const void* __restrict__ states, int fmt, int B,
                                                                                         const float* __restrict__ pk,
                                                                                         float* __restrict__ pooled,
-                                                                                        const uint8_t* __restrict__ active, int phase_delay) {
+                                                                                        const uint8_t* __restrict__ active, int phase_delay,
+                                                                                        int A = 0, float* __restrict__ logits = nullptr,
+                                                                                        float* __restrict__ policy = nullptr,
+                                                                                        float* __restrict__ value_pre = nullptr,
+                                                                                        float* __restrict__ value = nullptr) {
+    static_assert(!FUSE || JT == 1, "the fused heads are written for the 512-thread form");
     constexpr int N = 9, V = 81, S = 8;
     constexpr int NWV = 8 / JT;
     constexpr int NSLOT = NWV == 4 ? 3 : 2;
@@ -1058,7 +1181,17 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         linear_split<JT>(sm, Bf, lane, zh, zl);
         AQG_STAMP_AT(4)
         AQG_STAMP_AT(15)
-        aggregate_store<JT, true>(sm, zh, zl, out, wave, lane, prs, b * (HID * 4));
+        if constexpr (FUSE) {
+            // the board's heads, right here: the plane image is dead once every wave is past its layer-3 linear map (the barrier)
+            FusedHeadsScratch& hs = *reinterpret_cast<FusedHeadsScratch*>(&sm.P[0][0]);
+            __syncthreads();
+            aggregate_store<JT, true>(sm, zh, zl, out, wave, lane, prs, b * (HID * 4), hs.g);
+            __syncthreads();
+            fused_heads_512(hs, rs, pk, A, tid, logits ? logits + (size_t)b * A : nullptr, policy ? policy + (size_t)b * A : nullptr,
+                            value_pre ? value_pre + b : nullptr, value ? value + b : nullptr);
+        } else {
+            aggregate_store<JT, true>(sm, zh, zl, out, wave, lane, prs, b * (HID * 4));
+        }
         rec0 = nrec0; rec1 = nrec1;
         if (bn < B) __syncthreads();                                        // AF / X0 / sqd / dnv / planes are free for the next board
                                                                             // (bn is workgroup-uniform; the last board needs no barrier)
@@ -1402,6 +1535,10 @@ int g_trunk_phase_delay = 100;   // x 64 cycles: start offset of the second-resi
 int g_trunk_delay_min_boards = 2048;   // launches below this many boards start all workgroups together (tools/phase_scan.py:
                                        // +4 % at 2,048 boards, +8 % at 4,096, +15-19 % from 8,192 on the three-per-CU form)
 int g_trunk_grid = 0;      // 0 = default persistent grid; otherwise override (diagnostics)
+int g_fuse_heads = 0;      // 1: launches of <= FUSE_HEADS_MAX boards compute their boards' heads inside the trunk workgroups.  OFF by
+                           // default: measured 6.8 us per board on top of the trunk's 14.2 (a matrix-vector product per workgroup is five
+                           // barrier-separated L2 round trips) against 6.4 us for the separate 16-boards-per-workgroup MFMA launch that
+                           // other game sets' kernels can overlap; self-play fell from 1,516 to 1,157 games/s with it on
 
 // Diagnostic: fill every CU's LDS with NaN bit patterns so that any read-before-write in a later kernel shows up
 // deterministically (used by the parity tests; LDS contents are otherwise whatever the previous kernel left).
@@ -1463,6 +1600,7 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     const int A = N * N + 2 * (N - 1) * (N - 1);
     // persistent grid: 256 CUs x resident workgroups per CU, grid-stride over boards
     const int variant = (flags & 1) ? (g_trunk_variant == 0 ? 0 : 1) : g_trunk_variant;   // AQG_GNN_EXACT_F32
+    bool fused = false;
     if (g_profile_trunk) { (void)hipEventRecord(prof_event(), st); g_prof_boards += B; }
     if (variant == 0) {
         int grid = B < 256 ? B : 256;
@@ -1480,10 +1618,18 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
         // SIMD to hide each other's vector work, the highest throughput at every launch size (tools/trunk_scan.py)
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0);
+        const bool want_heads = logits || policy || value_pre || value;
+        if (want_heads && g_fuse_heads && B <= FUSE_HEADS_MAX && N * N + 2 * (N - 1) * (N - 1) <= APAD) {
+            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2, true>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, 0,
+                               N * N + 2 * (N - 1) * (N - 1), logits, policy, value_pre, value);
+            fused = true;
+        } else {
+            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0);
+        }
     }
     if (g_profile_trunk) (void)hipEventRecord(prof_event(), st);
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;
+    if (fused) return 0;                                        // the trunk workgroups did their boards' heads themselves
     if (!logits && !policy && !value_pre && !value) return 0;   // trunk only (bench: time the dominant kernel alone)
     if (variant >= 3 && A <= 14 * 16) {
         hipLaunchKernelGGL(gcn_heads_mm_kernel, dim3((B + 15) / 16), dim3(256), 0, st, (const float*)pooled, B, A, packed,

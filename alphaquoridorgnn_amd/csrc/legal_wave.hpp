@@ -41,10 +41,16 @@ __device__ __forceinline__ int wave_legal_actions(const QState& s, int lane, uin
     // chains keep a lone wavefront's VALU busy; one fill per lane and twice the rounds measured slower).
     const int cH = __popcll(nH), cV = __popcll(nV);
     const int ntask = cH + cV;
-    uint64_t failH = 0, failV = 0;
+    // Results go back without any cross-lane reduction: the task of candidate (H, slot L) ran in lane rank = number of
+    // needed H candidates below L (V candidates follow the H ones), so ONE ballot of "my task failed" per round of 64 tasks
+    // is all the exchange there is -- lane L (= slot L) looks its own two bits up.  (Six rounds of four ds_bpermute each, a
+    // dependent chain through the LDS crossbar, were a quarter of this function's latency.)
+    bool myfailH = false, myfailV = false;
+    const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int rankH = __popcll(nH & below), rankV = cH + __popcll(nV & below);
     for (int tbase = 0; tbase < ntask; tbase += 64) {
         const int task = tbase + lane;
-        uint64_t myfailH = 0, myfailV = 0;
+        bool failed = false;
         if (task < ntask) {
             const int k = task;
             const int orient = k < cH ? 1 : 2;
@@ -57,19 +63,16 @@ __device__ __forceinline__ int wave_legal_actions(const QState& s, int lane, uin
                 const int c = __popcll((m >> slot) & lowmask);
                 if (rank >= c) { rank -= c; slot += w; }
             }
-            const Open o = add_wall<N>(base, orient, slot);
-            const int me = s.ppos, other = V - 1 - s.epos;
-            const int ok = can_reach2<N>(o, me, other, mask_row<N>(0), other, me, mask_row<N>(N - 1));
-            if (ok != 3) { if (orient == 1) myfailH = 1ull << slot; else myfailV = 1ull << slot; }
+            // (the pawns are the same in every lane: as scalars, the jump-source positions of the searches are scalars too)
+            const int me = __builtin_amdgcn_readfirstlane((int)s.ppos), other = V - 1 - __builtin_amdgcn_readfirstlane((int)s.epos);
+            const int ok = can_reach2_w3<N>(base, orient, slot, me, other, mask_row<N>(0), other, me, mask_row<N>(N - 1));
+            failed = ok != 3;
         }
-        // wave-wide OR of the failure bits
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            myfailH |= ((uint64_t)(uint32_t)__shfl_xor((int)(myfailH >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)myfailH, off);
-            myfailV |= ((uint64_t)(uint32_t)__shfl_xor((int)(myfailV >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)myfailV, off);
-        }
-        failH |= myfailH; failV |= myfailV;
+        const uint64_t fm = __ballot(failed);               // bit t = task tbase + t failed
+        if (needH && rankH >= tbase && rankH < tbase + 64) myfailH = (fm >> (rankH - tbase)) & 1;
+        if (needV && rankV >= tbase && rankV < tbase + 64) myfailV = (fm >> (rankV - tbase)) & 1;
     }
+    const uint64_t failH = __ballot(myfailH), failV = __ballot(myfailV);
     const uint64_t mH = pH & ~failH, mV = pV & ~failV;
     const bool legH = (mH >> lane) & 1, legV = (mV >> lane) & 1;
 

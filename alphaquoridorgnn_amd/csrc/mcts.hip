@@ -34,7 +34,7 @@ size_t boards_any_workspace_floats(int N, int B);
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
                                   float* value, const uint8_t* active, int flags, hipStream_t st);
-extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, g_profile_trunk;
+extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, g_profile_trunk, g_fuse_heads;
 int g_use_graph = 1;       // aqg_set_option("use_graph", 0) forces plain launches
 
 __device__ __forceinline__ int wave_sum_i(int v) {
@@ -46,6 +46,43 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
+}
+
+// Wave-wide reductions on DPP (row operations inside the SIMD) instead of ds_bpermute shuffles through the LDS crossbar: the
+// step kernel is one wavefront's dependent chain, and a six-round bpermute reduction costs it more than the tree level's
+// arithmetic.  Result in an SGPR (lane 63 holds the total after the row_bcast steps).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWMASK, 0xf, false); }
+__device__ __forceinline__ float wave_max_dpp(float x) {       // max over the 64 lanes (NaN entries are ignored, like v_max_f32)
+    auto step = [](float v, int moved) { return fmaxf(v, __builtin_bit_cast(float, moved)); };
+    x = step(x, dpp_i<0xB1, 0xf>(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x)));     // quad_perm [1,0,3,2]
+    x = step(x, dpp_i<0x4E, 0xf>(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x)));     // quad_perm [2,3,0,1]
+    x = step(x, dpp_i<0x141, 0xf>(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x)));    // row_half_mirror
+    x = step(x, dpp_i<0x140, 0xf>(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x)));    // row_mirror: 16 lanes agree
+    x = step(x, dpp_i<0x142, 0xa>(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x)));    // row_bcast15 -> rows 1, 3
+    x = step(x, dpp_i<0x143, 0xc>(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x)));    // row_bcast31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+__device__ __forceinline__ int wave_sum_dpp(int x) {
+    x += dpp_i<0xB1, 0xf>(0, x);
+    x += dpp_i<0x4E, 0xf>(0, x);
+    x += dpp_i<0x141, 0xf>(0, x);
+    x += dpp_i<0x140, 0xf>(0, x);
+    x += dpp_i<0x142, 0xa>(0, x);
+    x += dpp_i<0x143, 0xc>(0, x);
+    return __builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ uint64_t rfl64(uint64_t v) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+// a game's state is the same in every lane of its wavefront: as scalars, next() / is_lose() / is_draw() run on the scalar unit
+__device__ __forceinline__ QState uniform_state(const QState& v) {
+    QState s;
+    s.hw = rfl64(v.hw); s.vw = rfl64(v.vw);
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)v.ppos | ((uint32_t)v.pwl << 8) | ((uint32_t)v.epos << 16) | ((uint32_t)v.ewl << 24)));
+    s.ppos = (uint8_t)(m & 0xff); s.pwl = (uint8_t)((m >> 8) & 0xff); s.epos = (uint8_t)((m >> 16) & 0xff); s.ewl = (uint8_t)(m >> 24);
+    s.plies = (uint16_t)__builtin_amdgcn_readfirstlane((int)v.plies); s.pad = 0;
+    return s;
 }
 
 // One reference-"Node" (pv_mcts.py:24-31) per 32-byte record: the statistics, the prior, the action that led here and
@@ -374,6 +411,15 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
 // deeper than `fast_depth` (61; never seen) fall back to that variant mid-flight: pending updates are flushed, fenced,
 // and the descent continues on memory (the tests run the goldens with fast_depth 1 and 2 to exercise every hand-over).
 // ------------------------------------------------------------------------------------------------
+// Diagnostic build only (-DAQG_STAMP, tools/stamp_step.py; never shipped): lane 0 of every game adds the cycles spent in each
+// phase of the step to pooled[g][2 i .. 2 i + 1] as u64 (the fake-evaluator runs the tool uses never touch `pooled`).
+#ifdef AQG_STAMP
+#define STEP_STAMP_DECL unsigned long long sp_prev = __builtin_readcyclecounter();
+#define STEP_STAMP(i) { const unsigned long long sp_now = __builtin_readcyclecounter(); if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[i] += sp_now - sp_prev; sp_prev = sp_now; }
+#else
+#define STEP_STAMP_DECL
+#define STEP_STAMP(i)
+#endif
 int g_step_variant = 1;
 int g_step_fast_depth = 61;
 
@@ -385,9 +431,10 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     int* path = e.path + (size_t)g * (e.sims + 2);
     const uint8_t* ord = e.legal_order + (size_t)g * MAX_LEGAL;
     const float* pol = e.policy + (size_t)g * A;
+    STEP_STAMP_DECL
     // ---------------- round 1
     const int active = e.game_active[g];
-    QState s = load_state(e.root_state, 1, g);
+    const QState s_loaded = load_state(e.root_state, 1, g);
     int flag = 0, depth_old = 0, cnt_new = 0, first_new = 0;
     float value = 0.f;
     uint8_t oa[3] = {0, 0, 0};
@@ -411,11 +458,18 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
 #pragma unroll
     for (int r = 0; r < 3; ++r) rc[r] = nodes[min(1 + lane + 64 * r, e.node_cap - 1)];
     if (!do_expand) flag = 0;
+    // (wave-uniform values the compiler cannot know to be uniform: as scalars they steer branches and v_readlane)
+    flag = __builtin_amdgcn_readfirstlane(flag); depth_old = __builtin_amdgcn_readfirstlane(depth_old);
+    cnt_new = __builtin_amdgcn_readfirstlane(cnt_new); first_new = __builtin_amdgcn_readfirstlane(first_new);
     if (flag != 1 && !do_select) return;
+#ifdef AQG_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STEP_STAMP(0)
 
     // ---------------- previous simulation: priors, new children, backup deltas (registers; stores issued, nothing re-read)
     const bool expanded = flag == 1 && cnt_new > 0 && first_new + cnt_new <= e.node_cap;
-    const int leaf_old = flag == 1 ? (depth_old < 64 ? __shfl(pnode, depth_old & 63) : path[depth_old]) : -1;
+    const int leaf_old = flag == 1 ? (depth_old < 64 ? __builtin_amdgcn_readlane(pnode, depth_old & 63) : path[depth_old]) : -1;
     float pl[3] = {0.f, 0.f, 0.f};
     if (flag == 1) {
         if (e.prior_mode == 0) {     // P0: gather at the legal actions, divide by the sum unless 0 (pv_network_cnn.py:129-132)
@@ -488,8 +542,10 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     if (!do_select) { flush_old(); return; }
     if (!active) { flush_old(); if (lane == 0) e.leaf_flag[g] = 0; return; }
     if (lane == 0) e.leaf_flag[g] = 0;
+    STEP_STAMP(1)
 
     // ---------------- descent (pv_mcts.py:33-66 via :69-78)
+    QState s = uniform_state(s_loaded);
     bool regs = true;                 // round-1 / register copies are current (false after a fall-back to memory)
     if (flag == 1 && !fast_old) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -533,7 +589,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
         if (cnt == 0) break;                                                         // pv_mcts.py:45 unexpanded leaf
         // the old path's child of this node: backup delta and (if it is the old leaf) its new child range, in registers
         const bool patch = regs && onpath && depth < depth_old;
-        const int pchild = patch ? __shfl(pnode, (depth + 1) & 63) : -1;
+        const int pchild = patch ? __builtin_amdgcn_readlane(pnode, (depth + 1) & 63) : -1;
         int t = 0;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -547,36 +603,42 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
                 t += rec[r].n;
             }
         }
-        t = wave_sum_i(t);
+        t = wave_sum_dpp(t);
         const float st = (float)sqrt((double)t);              // f32(math.sqrt(t))
-        float best = -INFINITY; int besti = 0x7fffffff;
+        float sc[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int i = lane + 64 * r;
-            if (i < cnt) {
-                const float u = ((e.c_puct * rec[r].p) * st) / (float)(1 + rec[r].n);
-                const float q = rec[r].n ? (float)(-rec[r].w / (double)rec[r].n) : 0.0f;
-                const float sc = q + u;
-                if (sc > best) { best = sc; besti = i; }       // strict > keeps the lowest index within a lane
+            sc[r] = -INFINITY;
+            if (64 * r < cnt) {                                // (wave-uniform: most nodes below the root have < 64 children)
+                const bool visited = __ballot(i < cnt && rec[r].n != 0) != 0;      // wave-uniform: any visited child in this slot?
+                if (i < cnt) {
+                    const float u = ((e.c_puct * rec[r].p) * st) / (float)(1 + rec[r].n);
+                    float q = 0.0f;
+                    if (visited) q = rec[r].n ? (float)(-rec[r].w / (double)rec[r].n) : 0.0f;   // (the float64 division is the long pole)
+                    sc[r] = q + u;
+                }
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {               // (max score, min index) across the wave
-            const float ob = __shfl_xor(best, off);
-            const int oi = __shfl_xor(besti, off);
-            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-        }
-        if (besti == 0x7fffffff) besti = 0;                    // all-NaN guard (np.argmax would return 0)
-        const int slot = besti >> 6, src = besti & 63;
+        // np.argmax: the first index of the maximum.  Wave maximum by DPP, then the lowest child index holding it from three
+        // ballots (children lane, lane + 64, lane + 128 in that order).  NaN scores never equal the maximum; if nothing
+        // matches (all NaN) child 0 is taken, as before.
+        const float best = wave_max_dpp(fmaxf(fmaxf(sc[0], sc[1]), sc[2]));
+        const uint64_t m0 = __ballot(lane < cnt && sc[0] == best), m1 = __ballot(lane + 64 < cnt && sc[1] == best),
+                       m2 = __ballot(lane + 128 < cnt && sc[2] == best);
+        const int besti = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 + __builtin_ctzll(m2) : 0));
+        const int slot = besti >> 6, src = besti & 63;          // wave-uniform: the winner's fields come by v_readlane
         const uint32_t k_sel = slot == 0 ? rec[0].kids : (slot == 1 ? rec[1].kids : rec[2].kids);
         const uint32_t a_sel = slot == 0 ? rec[0].action : (slot == 1 ? rec[1].action : rec[2].action);
         const double w_sel = slot == 0 ? rec[0].w : (slot == 1 ? rec[1].w : rec[2].w);
         const int n_sel = slot == 0 ? rec[0].n : (slot == 1 ? rec[1].n : rec[2].n);
-        kids = (uint32_t)__shfl((int)k_sel, src);
-        const int action = __shfl((int)a_sel, src);
+        kids = (uint32_t)__builtin_amdgcn_readlane((int)k_sel, src);
+        const int action = __builtin_amdgcn_readlane((int)a_sel, src);
         // the chosen child's current statistics travel to lane depth + 1 (used only if the path ends on a terminal node)
-        const double cw = __shfl(w_sel, src);
-        const int cn = __shfl(n_sel, src);
+        const uint64_t wbits = __builtin_bit_cast(uint64_t, w_sel);
+        const double cw = __builtin_bit_cast(double, ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wbits >> 32), src) << 32) |
+                                                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wbits, src));
+        const int cn = __builtin_amdgcn_readlane(n_sel, src);
         node = first + besti;
         onpath = onpath && depth < depth_old && node == pchild;
         s = next_state<N>(s, action);
@@ -591,8 +653,17 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             regs = false;
         }
+        // (Requesting the old path's next child block speculatively, before the scores are computed, was tried: the level
+        //  got 14 % SLOWER -- its arithmetic, not its load, is the long pole, and a wrong guess costs a second round.)
         fetch_children(kids, regs && onpath && depth == depth_old);
+#ifdef AQG_STAMP
+        if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[6] += 1;     // levels descended
+#endif
     }
+#ifdef AQG_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STEP_STAMP(2)
     if (terminal) {
         // backup of THIS simulation (pv_mcts.py:36-42).  Pending old-path stores go first; the new path's stores carry both
         // updates for the nodes the two paths share (same wavefront, same address: stores keep their order).
@@ -621,6 +692,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     } else {
         flush_old();
         const int total = wave_legal_actions<N>(s, lane, nullptr, e.legal_order + (size_t)g * MAX_LEGAL);
+        STEP_STAMP(3)
         if (lane == 0) {
             store_state(e.leaf_state, g, s);
             e.legal_count[g] = total;
@@ -628,6 +700,11 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
             e.leaf_flag[g] = 1;
         }
     }
+#ifdef AQG_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STEP_STAMP(4)
+    if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[7] += 1;         // steps
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -870,7 +947,7 @@ static int enqueue_sims(const aqg_engine& e, hipStream_t st) {
 // below and the library's other host-side globals are not synchronised.)
 struct SimGraph {
     aqg_engine e;
-    int opts[7];
+    int opts[8];
     hipGraphExec_t exec;
 };
 static std::vector<SimGraph> g_sim_graphs;
@@ -879,7 +956,7 @@ template <int N>
 static int run_sims(const aqg_engine& e, hipStream_t st) {
     if (!g_use_graph || g_profile_trunk || st == nullptr || e.sims < 4) return enqueue_sims<N>(e, st);
     // every option a captured launch bakes in is part of the key: a changed option must never replay a stale graph
-    const int opts[7] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth};
+    const int opts[8] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth, g_fuse_heads};
     for (const SimGraph& g : g_sim_graphs)
         if (!memcmp(&g.e, &e, sizeof(aqg_engine)) && !memcmp(g.opts, opts, sizeof(opts))) {
             if (hipGraphLaunch(g.exec, st) != hipSuccess) return fail("hipGraphLaunch");

@@ -287,6 +287,103 @@ template <int N> QHD int can_reach2(const Open& o, int sA, int obA, BB goalA, in
     return res;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same pair of searches on three 32-bit words per board (V <= 81 < 96 tiles) -- what the GPU runs.  One wavefront per
+// state means one LANE per candidate wall, alone on its SIMD: the search is a chain of dependent vector instructions and
+// its length is the latency of legal_actions().  Against the two-u64 form above: a shift by N is three v_alignbit_b32
+// instead of two 64-bit shifts + OR per half (64-bit shifts are slow), the jump landings are OR-ed in under an
+// all-ones / zero mask taken from the source tile's bit (no branches: the u64 form spends 60 scalar instructions per
+// round on exec-mask bookkeeping), and a round is ~115 vector instructions instead of ~235.  Same decisions as two
+// can_reach() calls (checked against it on every golden fixture by the host build, like can_reach2).
+// ---------------------------------------------------------------------------------------------
+struct W3 {
+    uint32_t a, b, c;        // tiles 0..31, 32..63, 64..95
+};
+QHD W3 w3(const BB& x) { W3 r; r.a = (uint32_t)x.lo; r.b = (uint32_t)(x.lo >> 32); r.c = (uint32_t)x.hi; return r; }
+QHD W3 w3_bit(int t) { W3 r; r.a = t < 32 ? 1u << t : 0u; r.b = (t >= 32 && t < 64) ? 1u << (t - 32) : 0u; r.c = t >= 64 ? 1u << (t - 64) : 0u; return r; }
+QHD W3 operator&(W3 x, W3 y) { W3 r; r.a = x.a & y.a; r.b = x.b & y.b; r.c = x.c & y.c; return r; }
+QHD W3 operator|(W3 x, W3 y) { W3 r; r.a = x.a | y.a; r.b = x.b | y.b; r.c = x.c | y.c; return r; }
+QHD W3 operator~(W3 x) { W3 r; r.a = ~x.a; r.b = ~x.b; r.c = ~x.c; return r; }
+QHD bool w3_any(W3 x) { return (x.a | x.b | x.c) != 0; }
+QHD bool w3_eq(W3 x, W3 y) { return ((x.a ^ y.a) | (x.b ^ y.b) | (x.c ^ y.c)) == 0; }
+template <int K> QHD W3 w3_shl(W3 x) {   // 0 < K < 32
+    W3 r; r.a = x.a << K; r.b = (x.b << K) | (x.a >> (32 - K)); r.c = (x.c << K) | (x.b >> (32 - K)); return r;
+}
+template <int K> QHD W3 w3_shr(W3 x) {
+    W3 r; r.a = (x.a >> K) | (x.b << (32 - K)); r.b = (x.b >> K) | (x.c << (32 - K)); r.c = x.c >> K; return r;
+}
+// all-ones if tile t is set in x, else zero
+QHD uint32_t w3_mask_of(W3 x, int t) {          // 0 <= t < 96
+    const uint32_t w = t < 32 ? x.a : (t < 64 ? x.b : x.c);
+    return 0u - ((w >> (t & 31)) & 1u);
+}
+
+// landing masks of the jump rule (game_logic.py:174-188) around obstacle e, branch-free: for direction d (0=U,1=D,2=L,3=R)
+// the tiles a pawn stepping onto e lands on instead, already AND-ed with "the source tile exists and its edge to e is open".
+// e is the same in every lane on the GPU (scalar tile masks); the open-edge boards differ per candidate wall.
+template <int N> QHD void jump_landings_w3(const W3& oU, const W3& oD, const W3& oL, const W3& oR, int e, W3 (&J)[4], int (&src)[4]) {
+    const int ex = e / N, ey = e % N;
+    auto clampt = [](int t) { return t < 0 ? 0 : (t > 95 ? 95 : t); };
+    const uint32_t tU = w3_mask_of(oU, e), tD = w3_mask_of(oD, e), tL = w3_mask_of(oL, e), tR = w3_mask_of(oR, e);
+    // (an open edge at e guarantees that the neighbour exists, so the neighbour masks need no range checks of their own)
+    const W3 bU = w3_bit(clampt(e - N)), bD = w3_bit(clampt(e + N)), bL = w3_bit(clampt(e - 1)), bR = w3_bit(clampt(e + 1));
+    auto sel = [](uint32_t m, const W3& x) { W3 r; r.a = x.a & m; r.b = x.b & m; r.c = x.c & m; return r; };
+    const W3 sideLR = sel(tL, bL) | sel(tR, bR), sideUD = sel(tU, bU) | sel(tD, bD);
+    const W3 jU = sel(tU, bU) | sel(~tU, sideLR), jD = sel(tD, bD) | sel(~tD, sideLR);
+    const W3 jL = sel(tL, bL) | sel(~tL, sideUD), jR = sel(tR, bR) | sel(~tR, sideUD);
+    src[0] = clampt(e + N); src[1] = clampt(e - N); src[2] = clampt(e + 1); src[3] = clampt(e - 1);
+    const uint32_t vU = (ex + 1 < N) ? w3_mask_of(oU, src[0]) : 0u;      // mover below the obstacle, moving up
+    const uint32_t vD = (ex - 1 >= 0) ? w3_mask_of(oD, src[1]) : 0u;     // mover above, moving down
+    const uint32_t vL = (ey + 1 < N) ? w3_mask_of(oL, src[2]) : 0u;      // mover to the right, moving left
+    const uint32_t vR = (ey - 1 >= 0) ? w3_mask_of(oR, src[3]) : 0u;     // mover to the left, moving right
+    J[0] = sel(vU, jU); J[1] = sel(vD, jD); J[2] = sel(vL, jL); J[3] = sel(vR, jR);
+}
+
+// `base` = open-edge boards of the position (wave-uniform on the GPU), plus ONE candidate wall (orient 1 = H / 2 = V at `slot`,
+// per lane; orient 0 = none).  Returns bit0 = A reaches its goal, bit1 = B reaches its goal.
+template <int N> QHD int can_reach2_w3(const Open& base, int orient, int slot, int sA, int obA, BB goalA, int sB, int obB, BB goalB) {
+    constexpr int S = N - 1;
+    W3 oU = w3(base.U), oD = w3(base.D), oL = w3(base.L), oR = w3(base.R);
+    {   // add_wall, branch-free: the wall's two blocked edges, both directions
+        const int t = slot + slot / S;                                  // top-left tile of the 2x2 block
+        const uint32_t mh = orient == 1 ? ~0u : 0u, mv = orient == 2 ? ~0u : 0u;
+        const W3 b0 = w3_bit(t), b1 = w3_bit(t + 1), bN = w3_bit(t + N), bN1 = w3_bit(t + N + 1);
+        auto clear = [](W3& x, const W3& m, uint32_t on) { x.a &= ~(m.a & on); x.b &= ~(m.b & on); x.c &= ~(m.c & on); };
+        clear(oD, b0 | b1, mh); clear(oU, bN | bN1, mh);
+        clear(oR, b0 | bN, mv); clear(oL, b1 | bN1, mv);
+    }
+    const W3 nA = ~w3_bit(obA), nB = ~w3_bit(obB);
+    const W3 gA = w3(goalA), gB = w3(goalB);
+    W3 JA[4], JB[4];
+    int qA[4], qB[4];
+    jump_landings_w3<N>(oU, oD, oL, oR, obA, JA, qA);
+    jump_landings_w3<N>(oU, oD, oL, oR, obB, JB, qB);
+    W3 rA = w3_bit(sA), rB = w3_bit(sB);
+    int res = 0, done = 0;
+    for (int it = 0; it < N * N; ++it) {
+        if (!(done & 1) && w3_any(rA & gA)) { res |= 1; done |= 1; }
+        if (!(done & 2) && w3_any(rB & gB)) { res |= 2; done |= 2; }
+        if (done == 3) break;
+        W3 a = (rA | w3_shl<N>(rA & oD) | w3_shr<N>(rA & oU) | w3_shl<1>(rA & oR) | w3_shr<1>(rA & oL)) & nA;
+        W3 b = (rB | w3_shl<N>(rB & oD) | w3_shr<N>(rB & oU) | w3_shl<1>(rB & oR) | w3_shr<1>(rB & oL)) & nB;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t mA = w3_mask_of(rA, qA[d]), mB = w3_mask_of(rB, qB[d]);
+            a.a |= JA[d].a & mA; a.b |= JA[d].b & mA; a.c |= JA[d].c & mA;
+            b.a |= JB[d].a & mB; b.b |= JB[d].b & mB; b.c |= JB[d].c & mB;
+        }
+        if (w3_eq(a, rA)) done |= 1;                       // fixpoint without the goal: this search has failed
+        if (w3_eq(b, rB)) done |= 2;
+        if (done == 3) break;
+        rA = a; rB = b;
+    }
+    if (!(done & 1) && w3_any(rA & gA)) res |= 1;
+    if (!(done & 2) && w3_any(rB & gB)) res |= 2;
+    return res;
+}
+
 // game_logic.py:120-192 legal_actions_pos(pos) with the enemy pawn on tile `e` (mover's frame).
 // Ordered: U, D, L, R; a jump contributes the straight landing, else (left,right) / (up,down).
 template <int N> QHD int legal_pos_list(const Open& o, int pos, int e, uint8_t* out) {
@@ -396,6 +493,8 @@ template <int N> QHD bool wall_keeps_paths(const QState& s, const Open& base, in
     // the lock-step form the GPU wavefront uses must decide exactly the same (host tests run this against every fixture)
     const int both = can_reach2<N>(o, me, other, mask_row<N>(0), other, me, mask_row<N>(N - 1));
     if (both != ((rp ? 1 : 0) | (re ? 2 : 0))) return !(rp && re);    // a disagreement flips the answer and fails the golden tests
+    const int both3 = can_reach2_w3<N>(base, orient, pos, me, other, mask_row<N>(0), other, me, mask_row<N>(N - 1));   // the three-word form the GPU runs
+    if (both3 != both) return !(rp && re);
     return rp && re;
 }
 

@@ -230,6 +230,21 @@ typedef struct aqg_train {
 int aqg_gcn_train_step(const aqg_train* t_host, const uint8_t* states72, const float* pi_target, const float* z_target,
                        int mode, void* stream);
 
+/* ------------------------------------------------------------------ CPU baseline agents (agents.py) -- HOST pointers, host code */
+
+/* The reference's baseline opponents (agents.py:14-214) are CPU code; so are these: the host instantiation of the rule header
+ * the kernels compile, exported from the same library.  `rec72_host` = one state72 record in HOST memory.
+ *   aqg_host_legal_actions   State.legal_actions() game_logic.py:103-117 -> ordered ids in out136_host[AQG_MAX_LEGAL], returns the count
+ *   aqg_host_next            State.next(action) game_logic.py:366-391
+ *   aqg_host_shortest_path   shortest_path_bfs agents.py:27-41: plies to the goal row over legal_actions_pos (jumps, frozen enemy), -1 = none
+ *   aqg_host_heuristic_eval  heuristic_eval agents.py:22-54: (enemy's path - mover's path) / max_dist_from_goal
+ *   aqg_host_alpha_beta_action  alpha_beta_action agents.py:60-108: depth-limited negamax with that heuristic, first best action; -1 = none */
+int aqg_host_legal_actions(int board_size, const uint8_t* rec72_host, uint8_t* out136_host);
+int aqg_host_next(int board_size, const uint8_t* rec72_host, int action, uint8_t* out72_host);
+int aqg_host_shortest_path(int board_size, const uint8_t* rec72_host);
+double aqg_host_heuristic_eval(int board_size, const uint8_t* rec72_host, int max_dist_from_goal);
+int aqg_host_alpha_beta_action(int board_size, const uint8_t* rec72_host, int plies_for_draw, int max_dist_from_goal, int max_depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,6 +179,18 @@ def test_gnn_forward_boards_vs_fp64_oracle(dev, variant):
         _lib.poison_lds(dev)
         p2, v2 = model.forward_states(torch.from_numpy(recs[:B]).to(dev))
         assert torch.equal(p2, policy[:B]) and torch.equal(v2, value[:B])
+    if variant in (3, 6):
+        # option "fuse_heads": launches of <= 1024 boards compute the heads inside the trunk workgroups (exact f32, one board
+        # per workgroup; off by default -- slower) instead of the 16-boards-per-workgroup MFMA heads kernel: both against the oracle
+        _lib.set_option("fuse_heads", 1)
+        try:
+            _lib.poison_lds(dev)
+            p3, v3, l3, vp3 = model.forward_states(torch.from_numpy(recs).to(dev), want_logits=True)
+            np.testing.assert_allclose(l3.cpu().numpy(), ref["logits"], atol=1e-5, rtol=1e-4)
+            np.testing.assert_allclose(vp3.cpu().numpy(), ref["value_pre"], atol=1e-5, rtol=1e-4)
+            np.testing.assert_allclose(p3.cpu().numpy(), ref["policy"], atol=1e-6, rtol=1e-4)
+        finally:
+            _lib.set_option("fuse_heads", 0)
     _lib.set_option("trunk_variant", 3)
 
 

@@ -258,3 +258,49 @@ def test_history_file_format_interoperates_with_reference(tmp_path, monkeypatch)
     # the six feature planes the reference's featuriser builds from those states sum to the recorded checksum
     from oracle import gnn as og
     assert abs(sum(float(og.node_features(r).sum()) for r in want) - doc["train_planes_sum"]) < 1e-9
+
+
+@pytest.mark.parametrize("N", [3, 5, 9])
+def test_baseline_agents_match_reference(N):
+    """random / alpha-beta / rollout-MCTS opponents (agents.py:14-214).  tests/golden/agents_*.npz hold what the
+    REAL reference agents answered on positions from random play (tools/gen_golden_agents.py; Python's `random` seeded per
+    call): heuristic_eval as a float, alpha_beta_action at depth 1 and 2, random_action and mcts_action under the recorded
+    seeds.  Ours are host code over the rule header the kernels compile -- every answer must be identical."""
+    import random
+    from alphaquoridorgnn_amd import agents
+    from alphaquoridorgnn_amd.game_logic import State
+    g = U.golden(f"agents_{N}x{N}.npz")
+    assert int(g["board"][0]) == N
+
+    def mk(rec):
+        return State(board_size=N, player=[int(rec[0]), int(rec[1])], enemy=[int(rec[2]), int(rec[3])],
+                     walls=[int(x) for x in rec[4:4 + (N - 1) ** 2]], plies_played=int(rec[68]) | (int(rec[69]) << 8))
+    assert agents._max_dist(mk(g["states"][0])) == int(g["max_dist"][0])
+    for i, rec in enumerate(g["states"]):
+        s = mk(rec)
+        assert agents.heuristic_eval(s) == g["heuristic"][i], i
+        assert agents.alpha_beta_action(s, 2) == int(g["ab2"][i]) and agents.alpha_beta_action(s, 1) == int(g["ab1"][i]), i
+        random.seed(int(g["random_seed"][i]))
+        assert agents.random_action(s) == int(g["random"][i]), i
+        # the host rules agree with the oracle's on the way (legal list, shortest path >= 0 unless walled in)
+        from oracle import quoridor as oq
+        assert agents._legal(s) == [int(a) for a in oq.State(rec).legal_actions()]
+    for j, i in enumerate(g["mcts_index"]):
+        random.seed(int(g["mcts_seed"][j]))
+        assert agents.mcts_action(mk(g["states"][i])) == int(g["mcts_action"][j]), i
+
+
+def test_baseline_agents_play_a_game():
+    """evaluate_agents.py-style use: alpha-beta (depth 1) against the random agent on 5x5 until the game ends."""
+    import random
+    from alphaquoridorgnn_amd import agents
+    from alphaquoridorgnn_amd.game_logic import State
+    random.seed(3)
+    s = State(board_size=5, num_walls=2)
+    plies = 0
+    while not s.is_done():
+        a = agents.alpha_beta_action(s, 1) if s.is_first_player() else agents.random_action(s)
+        assert a in agents._legal(s)
+        s = s.next(a)
+        plies += 1
+    assert 4 <= plies <= 28

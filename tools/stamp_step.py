@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Diagnostic: build with -DAQG_STAMP and print where the cycles of the fused MCTS step go (per game and simulation,
+averaged over 512 games x a few moves; fake evaluator).  Read the SHARES, not the absolute run time of this build."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+so = "/tmp/libaqgnn_hip_stamp.so"
+src = os.path.join(ROOT, "alphaquoridorgnn_amd", "csrc")
+subprocess.check_call(f"cd {src} && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DAQG_STAMP "
+                      f"legal_mask.hip gcn_forward.hip gcn_train.hip mcts.hip capi.hip -o {so} -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib 2>/dev/null", shell=True)
+os.environ["AQG_LIB_PATH"] = so
+import torch
+from alphaquoridorgnn_amd import _lib
+from alphaquoridorgnn_amd.engine import BatchedSelfPlay
+dev = _lib.require_gpu("cuda:0")
+_lib.set_option("use_graph", 0)
+for warm_moves, moves in ((0, 4), (20, 4), (60, 4)):
+    eng = BatchedSelfPlay(None, num_games=512, sims=200, evaluator="fake", fake_bias=0, record_history=False)
+    for _ in range(warm_moves):
+        eng.move()
+    eng.t["pooled"].zero_()
+    for _ in range(moves):
+        eng.move()
+    torch.cuda.synchronize()
+    raw = eng.t["pooled"].view(torch.int64).view(512, 64)[:, :8].double().cpu()
+    steps = raw[:, 7].sum().item()
+    names = ["round-1 loads landed", "expand + old backup (issue)", "descent (all levels)", "legal actions of the leaf", "tail stores landed"]
+    tot = raw[:, :5].sum().item()
+    print(f"after {warm_moves} moves: {steps:.0f} game-steps, {tot / steps:.0f} cycles per step, {raw[:, 6].sum().item() / steps:.2f} levels per descent")
+    for i, n in enumerate(names):
+        print(f"   {n:30s} {raw[:, i].sum().item() / steps:9.0f} cycles  {100 * raw[:, i].sum().item() / tot:5.1f} %")
