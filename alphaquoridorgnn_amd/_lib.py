@@ -50,6 +50,7 @@ SIGNATURES = {
     "aqg_last_error": (_c.c_char_p, []),
     "aqg_set_option": (_c.c_int, [_c.c_char_p, _c.c_int]),
     "aqg_debug_poison_lds": (_c.c_int, [_vp]),
+    "aqg_debug_trace": (_c.c_int, [_vp, _c.c_uint]),
     "aqg_profile_collect": (_c.c_int, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_longlong), _c.POINTER(_c.c_longlong), _c.c_int]),
     "aqg_legal_actions": (_c.c_int, [_c.c_int, _vp, _c.c_int, _vp, _vp, _vp, _vp]),
     "aqg_state_next": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_int, _vp, _vp]),

@@ -21,6 +21,34 @@ inline int check_launch(const char* kernel) {
 
 constexpr int WAVE = 64;
 
+// Diagnostic build only (-DAQG_TRACE, tools/trace_overlap.py; never shipped): every workgroup of the three per-simulation
+// kernels logs {kernel id | tag, blockIdx, start, end} (s_memrealtime, 100 MHz) into a caller-supplied buffer whose first
+// word is the entry counter -- the only way to see which kernels of different game sets REALLY run side by side (rocprofv3's
+// kernel trace serialises the dispatches it intercepts).
+#ifdef AQG_TRACE
+#ifndef AQG_TRACE_TU
+#define AQG_TRACE_TU other
+#endif
+// (one copy per translation unit, under a per-file NAME: without relocatable device code every file is its own code object, and
+//  the runtime registers device variables by name -- two statics of the same name end up sharing one registration)
+#define AQG_CAT2(a, b) a##b
+#define AQG_CAT(a, b) AQG_CAT2(a, b)
+#define g_trace_buf AQG_CAT(g_trace_buf_, AQG_TRACE_TU)
+#define g_trace_cap AQG_CAT(g_trace_cap_, AQG_TRACE_TU)
+static __device__ unsigned long long* g_trace_buf = nullptr;
+static __device__ unsigned int g_trace_cap = 0;
+#define AQG_TRACE_BEGIN unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+#define AQG_TRACE_END(kid, tag) { __syncthreads(); if (threadIdx.x == 0 && g_trace_buf) { const unsigned int i = atomicAdd(reinterpret_cast<unsigned int*>(g_trace_buf), 1u); \
+    if (i < g_trace_cap) { unsigned long long* r = g_trace_buf + 1 + 4ull * i; r[0] = (unsigned long long)(kid); r[1] = (unsigned long long)(tag); r[2] = tr_t0; r[3] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)blockIdx.x << 48); } } }
+#define AQG_TRACE_SETTER(name) int name(void* buf, unsigned int cap) { unsigned long long* b = (unsigned long long*)buf; \
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &b, sizeof(b)) != hipSuccess) return -1; \
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace_cap), &cap, sizeof(cap)) == hipSuccess ? 0 : -1; }
+#else
+#define AQG_TRACE_BEGIN
+#define AQG_TRACE_END(kid, tag)
+#define AQG_TRACE_SETTER(name) int name(void*, unsigned int) { return 0; }
+#endif
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // state loader: fmt 0 = state72 record, 1 = packed 24-byte QState

@@ -15,6 +15,8 @@ extern int g_step_variant;
 extern int g_step_fast_depth;
 int profile_collect(double* total_ms, long long* launches, long long* boards, int reset);
 int launch_poison_lds(hipStream_t st);
+int set_trace_gcn(void* buf, unsigned int cap);
+int set_trace_mcts(void* buf, unsigned int cap);
 
 size_t packed_floats();
 int pack_weights_host(int N, const float* const* t, float* out);
@@ -65,6 +67,11 @@ int aqg_set_option(const char* name, int value) {
 }
 
 int aqg_debug_poison_lds(void* stream) { return launch_poison_lds((hipStream_t)stream); }
+
+int aqg_debug_trace(void* buffer, unsigned int capacity) {
+    if (set_trace_gcn(buffer, capacity) || set_trace_mcts(buffer, capacity)) return fail("aqg_debug_trace: hipMemcpyToSymbol");
+    return 0;
+}
 
 int aqg_profile_collect(double* total_ms_host, long long* launches_host, long long* boards_host, int reset) {
     return profile_collect(total_ms_host, launches_host, boards_host, reset);

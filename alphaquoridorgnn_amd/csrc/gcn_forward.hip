@@ -17,6 +17,7 @@
 // heads kernel: policy MLP 128->64->209 (+Softmax) and value MLP 128->64->1 (+Tanh), 16 boards per workgroup.
 //
 // graph kernels: the same network on an arbitrary (x, CSR, graph_ptr) batch -- generic boundary path.
+#define AQG_TRACE_TU gcn
 #include "aqg_common.hpp"
 #include <vector>
 
@@ -974,6 +975,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
                                                                                         float* __restrict__ value_pre = nullptr,
                                                                                         float* __restrict__ value = nullptr) {
     static_assert(!FUSE || JT == 1, "the fused heads are written for the 512-thread form");
+    AQG_TRACE_BEGIN
     constexpr int N = 9, V = 81, S = 8;
     constexpr int NWV = 8 / JT;
     constexpr int NSLOT = NWV == 4 ? 3 : 2;
@@ -1208,6 +1210,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         o[16] = (unsigned long long)st_n;
     }
 #endif
+    AQG_TRACE_END(2, (unsigned long long)(uintptr_t)pooled)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1364,6 +1367,7 @@ __global__ __launch_bounds__(256, 2) void gcn_heads_mm_kernel(const float* __res
                                                               float* __restrict__ policy, float* __restrict__ value_pre,
                                                               float* __restrict__ value, const uint8_t* __restrict__ active) {
     __shared__ HeadsSmem sm;
+    AQG_TRACE_BEGIN
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * 16;
@@ -1519,7 +1523,9 @@ __global__ __launch_bounds__(256, 2) void gcn_heads_mm_kernel(const float* __res
             for (int j = 0; j < 4; ++j) if (16 * (wave + 4 * j) + c < A) l[64 * j] = lg[j][i];
         }
     }
+    AQG_TRACE_END(3, (unsigned long long)(uintptr_t)pooled)
 }
+AQG_TRACE_SETTER(set_trace_gcn)
 
 // Trunk variants (aqg_set_option("trunk_variant", v)):
 //   0 exact f32-input MFMA + VALU gather, weights resident, 1 workgroup/CU      1 the same, 2 workgroups/CU

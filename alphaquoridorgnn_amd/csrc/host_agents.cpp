@@ -9,6 +9,9 @@
 //   aqg_host_alpha_beta_action               alpha_beta_action       agents.py:60-108 (depth-limited negamax, first best action wins)
 #include <cstdint>
 #include <cstring>
+#if defined(__HIPCC__) || defined(__HIP__)
+#include <hip/hip_runtime.h>      // (diagnostic one-command builds push this file through hipcc too; build.sh uses g++)
+#endif
 #include "quoridor_core.hpp"
 #include "../../include/aqgnn.h"
 

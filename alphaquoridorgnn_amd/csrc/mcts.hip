@@ -14,6 +14,7 @@
 // -> GNN trunk -> GNN heads on the leaf batch;
 // every game has exactly one leaf in flight, so no virtual loss is needed and per-game semantics equal the
 // sequential reference.
+#define AQG_TRACE_TU mcts
 #include "aqg_common.hpp"
 #include <vector>
 #include <cstring>
@@ -717,11 +718,13 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
 template <int N>
 __global__ __launch_bounds__(256) void engine_step_fast_kernel(aqg_engine e, int do_expand, int do_select, int fast_depth) {
     __shared__ float polbuf[4][256];
+    AQG_TRACE_BEGIN
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= e.num_games) return;
-    game_step_fast<N>(e, g, lane, do_expand, do_select, fast_depth, polbuf[threadIdx.x >> 6]);
+    if (g < e.num_games) game_step_fast<N>(e, g, lane, do_expand, do_select, fast_depth, polbuf[threadIdx.x >> 6]);
+    AQG_TRACE_END(1, (unsigned long long)(uintptr_t)e.pooled)
 }
+AQG_TRACE_SETTER(set_trace_mcts)
 
 template <int N>
 __global__ __launch_bounds__(256) void engine_step_kernel(aqg_engine e, int do_expand, int do_select) {

@@ -48,6 +48,10 @@ int aqg_profile_collect(double* total_ms_host, long long* launches_host, long lo
 /* Test aid: overwrite the LDS of every CU with NaN bit patterns (stream-ordered), so a kernel that reads LDS it
  * has not written fails deterministically instead of depending on what the previous kernel left behind. */
 int aqg_debug_poison_lds(void* stream);
+/* Diagnostic builds (-DAQG_TRACE) only; a no-op otherwise: every workgroup of the per-simulation kernels appends
+ * {kernel id, tag, start, end | blockIdx << 48} (u64 x 4, 100 MHz timestamps) to `buffer` (device memory, first u64 = entry
+ * counter, zeroed by the caller, room for `capacity` entries).  tools/trace_overlap.py. */
+int aqg_debug_trace(void* buffer, unsigned int capacity);
 
 /* ------------------------------------------------------------------ game rules (game_logic.py) */
 
