@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQG_LIB_PATH", os.path.join(_HERE, "libaqgnn_hip.so"))  # override: diagnostic builds only
 MAX_LEGAL = 136
 GNN_EXACT_F32 = 1        # AQG_GNN_EXACT_F32 (include/aqgnn.h)
-ABI_VERSION = 5
+ABI_VERSION = 6
+TRAIN_PART_FLOATS = 2 * 128 * 128 + 128 * 6 + 3 * 128    # AQG_TRAIN_PART_FLOATS, per position of the batch
 
 _c = ctypes
 _vp, _i32, _f32 = _c.c_void_p, _c.c_int32, _c.c_float
@@ -40,7 +41,7 @@ class TrainStruct(_c.Structure):
         [(n, _i32) for n in ("board_size", "batch", "policy_size", "step")]
         + [(n, _f32) for n in ("lr", "beta1", "beta2", "eps")]
         + [(n, _vp * 14) for n in ("params", "grads", "adam_m", "adam_v")]
-        + [(n, _vp) for n in ("x0", "ell_idx", "ell_w", "zbuf", "h1", "h2", "h3", "dh", "g", "dg", "hp", "hv", "dhp", "dhv",
+        + [(n, _vp) for n in ("h1", "h2", "h3", "zbuf", "dh", "g", "dg", "hp", "hv", "dhp", "dhv",
                               "lg", "pol", "vp", "val", "loss", "part")]
     )
 
@@ -71,6 +72,7 @@ SIGNATURES = {
     "aqg_engine_set_roots": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp]),
     "aqg_engine_root_visits": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp, _vp, _vp]),
     "aqg_gcn_train_step": (_c.c_int, [_c.POINTER(TrainStruct), _vp, _vp, _vp, _c.c_int, _vp]),
+    "aqg_gcn_train_steps": (_c.c_int, [_c.POINTER(TrainStruct), _vp, _vp, _vp, _vp, _c.c_longlong, _vp, _vp]),
     "aqg_host_legal_actions": (_c.c_int, [_c.c_int, _vp, _vp]),
     "aqg_host_next": (_c.c_int, [_c.c_int, _vp, _c.c_int, _vp]),
     "aqg_host_shortest_path": (_c.c_int, [_c.c_int, _vp]),

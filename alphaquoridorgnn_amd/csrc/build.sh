@@ -15,5 +15,5 @@ done
 ${CXX:-g++} -O2 -std=c++17 -fPIC -Wall -Wno-unknown-pragmas -c host_agents.cpp -o ${OBJDIR}/aqg_host_agents.o &
 objs+=(${OBJDIR}/aqg_host_agents.o)
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT "${objs[@]}" -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT "${objs[@]}"
 echo "built $(realpath $OUT)"

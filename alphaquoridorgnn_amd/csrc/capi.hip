@@ -44,6 +44,8 @@ int engine_move(const aqg_engine& e, const double* uniforms, hipStream_t st);
 int engine_search(const aqg_engine& e, const uint8_t* roots72, hipStream_t st);
 int engine_root_visits(const aqg_engine& e, int32_t* visits, uint8_t* actions, int32_t* count, hipStream_t st);
 int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, const float* z, int mode, hipStream_t st);
+int train_steps(const aqg_train& t, const uint8_t* states72, const float* pi, const float* z, const int64_t* order, long long positions,
+                float* loss_sums, hipStream_t st);
 }  // namespace aqg
 
 using namespace aqg;
@@ -171,6 +173,14 @@ int aqg_gcn_train_step(const aqg_train* t, const uint8_t* states72, const float*
         if (!t->params[i] || !t->grads[i] || (mode >= 1 && (!t->adam_m[i] || !t->adam_v[i]))) return fail("aqg_gcn_train_step: null parameter tensor");
     if (mode >= 1 && t->step < 1) return fail("aqg_gcn_train_step: step must be >= 1");
     return train_step(*t, states72, pi_target, z_target, mode, (hipStream_t)stream);
+}
+int aqg_gcn_train_steps(const aqg_train* t, const uint8_t* states72, const float* pi_target, const float* z_target, const int64_t* order,
+                        long long positions, float* loss_sums, void* stream) {
+    if (!t || !states72 || !pi_target || !z_target || positions < 0 || positions > 0x7fffffffLL) return fail("aqg_gcn_train_steps: bad argument");
+    for (int i = 0; i < 14; ++i)
+        if (!t->params[i] || !t->grads[i] || !t->adam_m[i] || !t->adam_v[i]) return fail("aqg_gcn_train_steps: null parameter tensor");
+    if (t->step < 1) return fail("aqg_gcn_train_steps: step must be >= 1");
+    return train_steps(*t, states72, pi_target, z_target, order, positions, loss_sums, (hipStream_t)stream);
 }
 
 }  // extern "C"

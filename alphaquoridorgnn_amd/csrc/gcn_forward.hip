@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_kernel(const
         b = bn;
     }
 #ifdef AQG_STAMP
-    if (blockIdx.x == 0 && tid == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(pooled + (size_t)B * HID);
         for (int i = 0; i < 16; ++i) o[i] = st_sum[i];
         o[16] = (unsigned long long)st_n;
@@ -983,9 +983,16 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     // The two workgroups resident on a CU run identical phase sequences; a start offset for the second-resident ones
     // (phase_delay x 64 cycles) keeps one on the matrix pipe while the other does vector work.
     for (int i = 0; i < (int)(blockIdx.x >> 8) * phase_delay; ++i) __builtin_amdgcn_s_sleep(1);   // 2nd / 3rd resident: 1x / 2x
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, q = lane >> 4;
+    // The thread index is NOT kept in a register across the board loop (at the 128-register cap the allocator spilled it and
+    // reloaded it behind an s_waitcnt vmcnt(0) that drained the weight prefetches): the wave index is a scalar, the lane index
+    // is re-derived from the execution mask (two v_mbcnt) wherever it is needed.
+    const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto fresh_lane = []() -> int {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    int wave = wave0;
 
     int b = blockIdx.x;
     while (b < B && active && !active[b]) b += gridDim.x;
@@ -995,8 +1002,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     // buffer loads off one SGPR descriptor + a scalar record offset: no 64-bit address registers to keep alive across the loop
     const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(states), 0, B * (fmt == 0 ? 72 : 24), 0x00020000);
     auto fetch_record = [&](int bb, uint32_t& r0, uint32_t& r1) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));          // offsets are recomputed per fetch, not kept (spilled) across the board loop
+        const int ln = fresh_lane();          // offsets are recomputed per fetch, not kept (spilled) across the board loop
         if (fmt == 0) {
             r0 = __builtin_amdgcn_raw_buffer_load_b8(rst, 4 + ln, bb * 72, 0);
             r1 = __builtin_amdgcn_raw_buffer_load_b32(rst, 0, bb * 72, 0);
@@ -1007,7 +1013,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     if (b < B) fetch_record(b, rec0, rec1);
     // once per workgroup: the padding rows no board ever writes.  No barrier here: their first reader sits behind the
     // first board's setup barrier.
-    if (tid < 15) { sm.sqd[81 + tid] = 0.f; sm.dnv[81 + tid] = 0.f; }
+    if (wave0 == 0) { const int l0 = fresh_lane(); if (l0 < 15) { sm.sqd[81 + l0] = 0.f; sm.dnv[81 + l0] = 0.f; } }
     u32x4 Bf[2][JT][4];
     const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pooled, 0, B * (HID * 4), 0x00020000);
@@ -1015,6 +1021,10 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     AQG_STAMP_DECL
     while (b < B) {
         AQG_STAMP_AT(7)
+        wave = wave0;
+        asm volatile("" : "+s"(wave));         // opaque per board: wave-derived predicates are recomputed (2-3 scalar ops), not
+                                               // hoisted out of the loop into registers that then spill
+        const int lane = fresh_lane(), tid = 64 * wave + lane, c = lane & 15, q = lane >> 4;
         // the small layer-1 weight fragment goes out first (lands under the setup)
         u32x4 w1f[JT];
 #pragma unroll
@@ -1079,8 +1089,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
                 const int blk = slot_block(it);
                 if (blk < AF_BLOCKS && lane < 32) {
                     const int kb = (AF_KB_PACK >> (2 * blk)) & 3;
-                    int l = lane;
-                    asm volatile("" : "+v"(l));
+                    const int l = fresh_lane();
                     const uint32_t deg = 1u + ((open_word(0, kb) >> l) & 1u) + ((open_word(1, kb) >> l) & 1u) +
                                          ((open_word(2, kb) >> l) & 1u) + ((open_word(3, kb) >> l) & 1u);
                     // fp16 of CQ / deg = 0.9375, 0.46875, 0.3125, 0.234375, 0.1875 (all exact)
@@ -1098,8 +1107,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
                 const int blk = slot_block(it);
                 if (blk < AF_BLOCKS) {
                     const int kb = (AF_KB_PACK >> (2 * blk)) & 3, nt = (AF_NT_PACK >> (3 * blk)) & 7;
-                    int ln = lane;
-                    asm volatile("" : "+v"(ln));      // opaque per board: no per-slot lane constant is kept alive (spilled) across the loop
+                    const int ln = fresh_lane();      // no per-slot lane constant is kept alive (spilled) across the loop
                     const int n = 16 * nt + (ln & 15), q = ln >> 4;
                     u32x4 fr = (u32x4){0u, 0u, 0u, 0u};
                     if (n < V) {
@@ -1204,7 +1212,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         b = bn;
     }
 #ifdef AQG_STAMP
-    if (blockIdx.x == 0 && tid == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(pooled + (size_t)B * HID);
         for (int i = 0; i < 16; ++i) o[i] = st_sum[i];
         o[16] = (unsigned long long)st_n;

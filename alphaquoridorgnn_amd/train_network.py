@@ -67,13 +67,12 @@ class GNNTrainer:
         B, V, A, H = self.max_batch, self.V, self.A, HIDDEN_DIM
         f = dict(dtype=torch.float32, device=self.dev)
         w = self.ws = dict(
-            x0=torch.empty((B * V, NUM_FEATURES), **f), ell_idx=torch.empty((B * V, 5), dtype=torch.int32, device=self.dev),
-            ell_w=torch.empty((B * V, 5), **f), zbuf=torch.empty((B * V, H), **f), h1=torch.empty((B * V, H), **f),
-            h2=torch.empty((B * V, H), **f), h3=torch.empty((B * V, H), **f), dh=torch.empty((B * V, H), **f),
+            h1=torch.empty((B * V, H), **f), h2=torch.empty((B * V, H), **f), h3=torch.empty((B * V, H), **f),
+            zbuf=torch.empty((B * V, H), **f), dh=torch.empty((B * V, H), **f),
             g=torch.empty((B, H), **f), dg=torch.empty((B, H), **f), hp=torch.empty((B, H // 2), **f),
             hv=torch.empty((B, H // 2), **f), dhp=torch.empty((B, H // 2), **f), dhv=torch.empty((B, H // 2), **f),
             lg=torch.empty((B, A), **f), pol=torch.empty((B, A), **f), vp=torch.empty((B,), **f), val=torch.empty((B,), **f),
-            loss=torch.empty((B, 2), **f), part=torch.empty((64 * (2 * 128 * 128 + 128 * 8 + 3 * 128),), **f))
+            loss=torch.empty((B, 2), **f), part=torch.empty((B * _lib.TRAIN_PART_FLOATS,), **f))
         t = self.t = _lib.TrainStruct()
         t.board_size, t.policy_size = self.N, self.A
         t.beta1, t.beta2, t.eps = float(betas[0]), float(betas[1]), float(eps)
@@ -132,6 +131,31 @@ class GNNTrainer:
         """(policy [B,A], value [B]) of the last step's forward pass."""
         return self.ws["pol"][:B], self.ws["val"][:B]
 
+    def run_epoch(self, states72, pi_target, z_target, order, lr=LEARNING_RATE, batch=None, pre_shuffle=True):
+        """All optimisation steps of one epoch in ONE library call (single process): step i trains on the positions
+        order[i*batch:(i+1)*batch] of the resident device arrays (train_network.py:72-95; the short last batch is kept, as
+        DataLoader does).  Returns the epoch's summed (policy_loss, value_loss) as a device tensor [2] -- no host sync."""
+        batch = self.max_batch if batch is None else int(batch)
+        if batch > self.max_batch:
+            raise ValueError("batch larger than the trainer's workspace")
+        n = int(order.shape[0])
+        sums = torch.zeros((2,), dtype=torch.float32, device=self.dev)
+        if n == 0:
+            return sums
+        # The shuffle is applied ONCE per epoch (three gathers, ~1 KB per position) and the steps then index the shuffled
+        # copies directly: every kernel of a step starts with cold loads, and reading order[] first would put one more
+        # HBM round trip in front of each of them.  (The C entry point also takes the order itself: order != NULL.)
+        order = order.to(self.dev, torch.int64).contiguous()
+        if pre_shuffle:
+            states72, pi_target, z_target = (x.index_select(0, order).contiguous() for x in (states72, pi_target, z_target))
+        self.t.batch, self.t.step, self.t.lr = batch, self.step_count + 1, float(lr)
+        _lib.check(self.lib.aqg_gcn_train_steps(ctypes.byref(self.t), _lib.ptr(states72), _lib.ptr(pi_target), _lib.ptr(z_target),
+                                                None if pre_shuffle else _lib.ptr(order), n, _lib.ptr(sums),
+                                                _lib.stream_ptr(self.dev)), "aqg_gcn_train_steps")
+        self.step_count += (n + batch - 1) // batch
+        self.model.invalidate_packed()
+        return sums
+
 
 def train_network():
     """train_network.py:26-107 on the GNN: best.pth -> NUM_EPOCH epochs over the newest .history -> latest.pth.
@@ -159,13 +183,16 @@ def train_network():
                 perm_h = perm.cpu()
                 dist.broadcast(perm_h, src=0)
                 perm = perm_h.to('cuda')
-        epoch_policy_loss = torch.zeros((), device='cuda')
-        epoch_value_loss = torch.zeros((), device='cuda')
-        for i in range(0, n, BATCH_SIZE):
-            idx = perm[i:i + BATCH_SIZE][rank::world]
-            pl, vl = trainer.step(s[idx], p[idx], v[idx], lr=lr)
-            epoch_policy_loss += pl
-            epoch_value_loss += vl
+        if world == 1:
+            epoch_policy_loss, epoch_value_loss = trainer.run_epoch(s, p, v, perm, lr=lr)
+        else:
+            epoch_policy_loss = torch.zeros((), device='cuda')
+            epoch_value_loss = torch.zeros((), device='cuda')
+            for i in range(0, n, BATCH_SIZE):
+                idx = perm[i:i + BATCH_SIZE][rank::world]
+                pl, vl = trainer.step(s[idx], p[idx], v[idx], lr=lr)
+                epoch_policy_loss += pl
+                epoch_value_loss += vl
         if rank == 0:
             print(f"\rEpoch {epoch + 1}/{NUM_EPOCH} | Policy Loss: {float(epoch_policy_loss):.4f} | Value Loss: {float(epoch_value_loss):.4f}", end='')
     if rank == 0:

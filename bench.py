@@ -7,8 +7,16 @@ rank per GPU (RCCL).  One STEP = one self-play generation on every rank: `--game
 (default 200) and the random-weight GNN as evaluator, followed by the generation's single exchange step -- the
 all-gather of the (s, pi, z) tuples over RCCL/xGMI (configs[3]).  Weak scaling: per-GPU work is fixed.
 
+`--backend gloo` swaps RCCL for gloo (host tensors) so that the N > 1 path can be rehearsed with several ranks on one GPU.
+
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   gnn_forward  : configs[1] -- pv_network_gnn forward at B=4096 synthetic boards, boards/s (HIP events)
+  step_kernel  : the fused MCTS step (engine_step_fast_kernel): latency-bound, so its entry is us per launch at 512 and
+                 4,096 games (HIP events over 160 back-to-back launches on mid-game trees), wavefronts per SIMD and
+                 game-steps/s instead of a bandwidth fraction
+  slot_refill  : the same slots with refill (quota = 3 x games: a finished game's slot takes the next game) against the
+                 lock-step generation of the headline number
+  train_step   : SURVEY 8(f).1, one epoch call of 200 steps at batch 128, with its own matrix-pipe roofline
   roofline     : the dominant kernel (gcn_trunk_boards_mm_kernel) over the timed region: algorithmic FLOP of the
                  boards it processed / its summed launch durations (HIP event pairs recorded inside the library around
                  the trunk launches of sampled moves -- one game set running alone, plain launches --, on the launch stream), against the matrix-pipe roof of the
@@ -43,6 +51,9 @@ PEAK_HBM = 8.0e12
 # WRITE_SIZE, separate passes; profiles/r01_trunk_mm_hbm_pmc.csv, B = 65,536 boards per launch).  PMC counters
 # cannot be collected from inside this process, so `roofline.traffic` = this per-board figure x boards per launch.
 TRUNK_HBM_BYTES_PER_BOARD_PMC = 852
+# training step, per position: forward trunk + the three weight gradients (same contractions) + the two data gradients
+# (layers 3, 2) + six aggregations (5 terms x 81 nodes x 128 columns) + the heads forward and twice backward
+TRAIN_FLOP_PER_POSITION = 2 * TRUNK_FLOP_PER_BOARD + 2 * (2 * 81 * 128 * 128) + 6 * (2 * 81 * 5 * 128) + 3 * (FWD_FLOP_PER_BOARD - TRUNK_FLOP_PER_BOARD)
 
 
 def cpu_baseline(sims, mean_plies, budget_s=15.0):
@@ -79,6 +90,10 @@ def main():
     ap.add_argument("--trunk-variant", type=int, default=3, help="developer knob: aqg_set_option trunk_variant (3 = per-launch choice)")
     ap.add_argument("--trunk-grid", type=int, default=0, help="developer knob: cap the trunk's persistent grid (0 = default 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend for N > 1: nccl = RCCL over xGMI (default); gloo = host tensors, for rehearsing "
+                         "several ranks on one GPU")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the step-kernel / slot-refill / training legs (profiling runs)")
     ap.add_argument("--large-games", type=int, default=16384,
                     help="extra single-GPU leg: one generation at this many concurrent games (north star: >= 10k); 0 = skip")
     args = ap.parse_args()
@@ -88,10 +103,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    local = local % max(torch.cuda.device_count(), 1)        # gloo rehearsal: more ranks than GPUs share the card
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from alphaquoridorgnn_amd import _lib
     from alphaquoridorgnn_amd.engine import BatchedSelfPlay, MultiSetSelfPlay, gather_history
@@ -117,6 +136,7 @@ def main():
                                       # other plies replay captured hipGraphs with all sets overlapping, where an event pair
                                       # would time the sharing, not the kernel.  Costs ~1-2 % of the timed region.
     sample_no = [0]
+    last_plies = [0]
 
     def _before(e):
         sampled_boards.sub_(e.t["stat_leaf_evals"].sum())    # boards evaluated by the sampled launches, counted on the device
@@ -144,6 +164,7 @@ def main():
                     break
         st, vis, z = eng.history_tensors()
         st, vis, z = gather_history(st, vis, z)       # the generation's one exchange step (RCCL all-gather)
+        last_plies[0] = ply
         return eng.counters(), int(st.shape[0])
 
     for _ in range(args.warmup):
@@ -162,7 +183,7 @@ def main():
     trunk_ms, trunk_launches, trunk_rows = _lib.profile_collect(reset=True)
     trunk_boards = int(sampled_boards.sum().item())    # boards evaluated inside the event-bracketed launches
 
-    tt = torch.tensor([elapsed, float(games), float(leaf_evals)], dtype=torch.float64, device=dev)
+    tt = torch.tensor([elapsed, float(games), float(leaf_evals)], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -183,28 +204,96 @@ def main():
     def fwd():
         _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(boards), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None,
                                               _lib.ptr(value), 0, _lib.stream_ptr(dev)), "fwd")
-    variants = {}
-    for name, v in (("f32_mfma_exact", 1), ("f16_split_mm_8wave_x2", 6), ("f16_split_mm_4wave_x3", 4)):
-        _lib.set_option("trunk_variant", v)
-        ms = time_ms(fwd, 100, warmup=10)
-        variants[name] = {"boards_per_s": B / (ms * 1e-3), "ms": ms}
+    # every variant is timed three times in interleaved order and its best time kept: a single pass right after the pools
+    # were freed under-reported the exact-f32 kernel by 3.4x in the round-1 driver run (4.96 M vs 17 M boards/s here)
+    names = (("f32_mfma_exact", 1), ("f16_split_mm_8wave_x2", 6), ("f16_split_mm_4wave_x2", 5))
+    variants = {n: {"ms": float("inf")} for n, _ in names}
+    for rep in range(3):
+        for name, v in names:
+            _lib.set_option("trunk_variant", v)
+            variants[name]["ms"] = min(variants[name]["ms"], time_ms(fwd, 60, warmup=10))
+    for name in variants:
+        variants[name]["boards_per_s"] = B / (variants[name]["ms"] * 1e-3)
     _lib.set_option("trunk_variant", 3)
-    fwd_ms = time_ms(fwd, 200, warmup=20)             # default variant, after the clocks have settled on this workload
+    fwd_ms = min(time_ms(fwd, 200, warmup=20) for _ in range(2))      # default variant, after the clocks have settled on this workload
 
-    # ---- next-row leg: train_network.py's optimisation step on the GNN, batch 128 (train_network.py:15)
-    from alphaquoridorgnn_amd.train_network import GNNTrainer, BATCH_SIZE
-    tr_model = GNNNetwork().to(dev)
-    trainer = GNNTrainer(tr_model, max_batch=BATCH_SIZE)
-    tb = boards[:BATCH_SIZE]
-    tpi = torch.softmax(torch.randn((BATCH_SIZE, 209), device=dev), dim=1)
-    tz = torch.randint(-1, 2, (BATCH_SIZE,), device=dev).float()
-    train_ms = time_ms(lambda: trainer.step(tb, tpi, tz), 50, warmup=5)
-    train_leg = {"workload": "train_network.py step on the GNN: forward + CE(softmaxed policy) + MSE + backward + Adam, fp32, batch 128",
-                 "ms_per_step": train_ms, "positions_per_s": BATCH_SIZE / (train_ms * 1e-3)}
-    del trainer, tr_model
+    step_leg = refill_leg = train_leg = None
+    if world == 1 and not args.no_extra_legs:
+        import ctypes
+        # ---- the fused MCTS step kernel alone: one wavefront per game, one dependent chain of loads per tree level
+        step_leg = {"kernel": "engine_step_fast_kernel<9> (backup + expansion of the previous simulation, PUCT descent, legal moves of the leaf)",
+                    "bound": "latency", "us_per_launch": {}, "game_steps_per_s": {}, "waves_per_simd": {}}
+        for G in (512, 4096):
+            # the fake evaluator (uniform priors, value 0) leaves the step kernel as the only per-simulation launch: a move is
+            # one graph replay of sims back-to-back step launches, so move time / sims = the launch-to-launch period
+            e1 = BatchedSelfPlay(None, num_games=G, sims=args.sims, evaluator="fake", fake_bias=0, seed=5, record_history=False)
+            for _ in range(20):
+                e1.move()                                     # plies 0-19: openings (up to 131 legal moves per node)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            for _ in range(40):
+                e1.move()                                     # plies 20-59: the middle game, where most of a generation's time goes
+            torch.cuda.synchronize()
+            us = (time.time() - t1) / (40 * args.sims) * 1e6
+            step_leg["us_per_launch"][str(G)] = us
+            step_leg["game_steps_per_s"][str(G)] = G / (us * 1e-6)
+            step_leg["waves_per_simd"][str(G)] = G / 1024.0
+            del e1
+        step_leg["note"] = ("launch-to-launch period over plies 20-59 of fake-evaluator games (40 moves x sims launches, hipGraph replay); one "
+                            "wavefront per game; per simulation ONE round of dependent loads (root record + root children + the previous "
+                            "leaf's policy, everything else patched in registers) plus one per tree level below the root; no bandwidth or "
+                            "FLOP roof applies (PMC: profiles/r02_pmc_summary.csv) -- the figure of merit is us per launch, which the "
+                            "chain step -> trunk -> heads pays once per simulation")
+        # ---- slot refill: the same 2048 slots, 3 x 2048 games; a finished game's slot takes the next game
+        torch.cuda.empty_cache()
+        er = MultiSetSelfPlay(model, num_games=args.games, sims=args.sims, num_sets=args.sets, seed=4242, quota=3 * args.games)
+        er.move(); er.sync(); torch.cuda.synchronize()
+        er.reset()
+        t1 = time.time()
+        cr = er.play_generation()
+        torch.cuda.synchronize()
+        dtr = time.time() - t1
+        rpos = int(er.history_tensors()[0].shape[0])
+        rplies = max(e2.moves_done for e2 in er.sets)
+        refill_leg = {"workload": f"{3 * args.games} games on {args.games} slots x {args.sims} sims/move, refilled as games end (engine quota)",
+                      "games_per_s": cr["finished"] / dtr, "s": dtr, "games": cr["finished"], "positions": rpos, "plies_played": rplies,
+                      "slot_utilisation": rpos / max(1.0, float(args.games) * rplies),
+                      "lockstep_slot_utilisation": positions / max(1.0, float(args.games * world) * last_plies[0]),
+                      "note": "slot_utilisation = positions played / (slots x plies the engine ran). Refill keeps the slots busy but mixes game "
+                              "phases inside every step launch, and a launch lasts as long as its slowest wavefront (an opening position with "
+                              "~130 legal moves); the lock-step generation of the headline value keeps all games in the same phase"}
+        del er
+        torch.cuda.empty_cache()
+        # ---- next-row leg: train_network.py's optimisation step on the GNN, batch 128 (train_network.py:15)
+        from alphaquoridorgnn_amd.train_network import GNNTrainer, BATCH_SIZE
+        tr_model = GNNNetwork().to(dev)
+        trainer = GNNTrainer(tr_model, max_batch=BATCH_SIZE)
+        nsteps = 200
+        tb = synth_states(BATCH_SIZE * nsteps, seed=3, dev=dev)
+        tpi = torch.softmax(torch.randn((BATCH_SIZE * nsteps, 209), device=dev), dim=1)
+        tz = torch.randint(-1, 2, (BATCH_SIZE * nsteps,), device=dev).float()
+        order = torch.randperm(BATCH_SIZE * nsteps, device=dev)
+        trainer.run_epoch(tb, tpi, tz, order[:BATCH_SIZE * 10])
+        torch.cuda.synchronize()
+        t1 = time.time()
+        trainer.run_epoch(tb, tpi, tz, order)
+        torch.cuda.synchronize()
+        train_ms = (time.time() - t1) / nsteps * 1e3
+        step_ms = time_ms(lambda: trainer.step(tb[:BATCH_SIZE], tpi[:BATCH_SIZE], tz[:BATCH_SIZE]), 50, warmup=5)
+        tflops = BATCH_SIZE * TRAIN_FLOP_PER_POSITION / (train_ms * 1e-3) / 1e12
+        train_leg = {"workload": "train_network.py epoch on the GNN: forward + CE(softmaxed policy) + MSE + backward + Adam, fp32, batch 128, "
+                                 f"{nsteps} steps in one aqg_gcn_train_steps call (shuffle applied once per epoch)",
+                     "ms_per_step": train_ms, "positions_per_s": BATCH_SIZE / (train_ms * 1e-3), "ms_per_step_single_calls": step_ms,
+                     "launches_per_step": 7,
+                     "roofline": {"kernel": "train_fwd12/fwd3/heads/bwd<3,2,1>/final (f32 MFMA 16x16x4)", "bound": "mfma", "achieved": tflops,
+                                  "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": tflops * 1e12 / PEAK_F32_MFMA,
+                                  "flop_per_position": TRAIN_FLOP_PER_POSITION,
+                                  "note": "2.2 GFLOP per step in 7 dependent launches that each start from a cold L2 (the previous launch ran on "
+                                          "other XCDs): the step is latency-bound, profiles/r02_train_step_*.{csv,log}"}}
+        del trainer, tr_model
 
     large = None
-    if world == 1 and args.large_games > 0:
+    if world == 1 and args.large_games > 0 and not args.no_extra_legs:
         del eng
         torch.cuda.empty_cache()
         eng = MultiSetSelfPlay(model, num_games=args.large_games, sims=args.sims, num_sets=args.sets, seed=77)
@@ -270,7 +359,12 @@ def main():
                                  "inside the MCTS are ~2,000 boards = 4 per CU, so avg_launch_us carries the wave-quantisation tail; "
                                  "gnn_forward.trunk_variants is the same kernel at 4,096 boards per launch"},
         }
-        out["train_step"] = train_leg
+        if step_leg is not None:
+            out["step_kernel"] = step_leg
+        if refill_leg is not None:
+            out["slot_refill"] = refill_leg
+        if train_leg is not None:
+            out["train_step"] = train_leg
         if large is not None:
             out["large_batch"] = large
         if world == 1 and not args.no_cpu_baseline:

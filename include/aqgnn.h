@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define AQG_MAX_LEGAL 136 /* >= 5 pawn moves + 128 wall placements */
-#define AQG_ABI_VERSION 5
+#define AQG_ABI_VERSION 6
 
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
@@ -206,33 +206,39 @@ int aqg_engine_root_visits(const aqg_engine* e_host, int32_t* visits, uint8_t* a
 
 /* One optimisation step on a batch of positions: forward, the reference's losses (CrossEntropyLoss applied to the
  * already-softmaxed policy with probability targets train_network.py:54,85 + MSELoss on the tanh value :55,86),
- * backward, and torch.optim.Adam's update (:56,:90-92).  fp32 throughout.  mode 0 = gradients only (into grads),
+ * backward, and torch.optim.Adam's update (:56,:90-92).  fp32 throughout, every contraction over the node rows on the
+ * f32 matrix pipe; seven launches per step (csrc/gcn_train.hip).  mode 0 = gradients only (into grads),
  * 1 = gradients + update, 2 = update only from whatever grads holds -- data-parallel training computes local gradients
  * (mode 0), all-reduces them over RCCL, and applies them (mode 2).  The 14 parameter tensors
  * are the state_dict tensors themselves in their PyTorch layouts and in the key order of KEYS in INTEGRATION.md; grads,
  * adam_m, adam_v have the same shapes.  All memory is the caller's (device pointers); nothing allocates or synchronises.
- * B = batch, V = board_size^2, A = policy size. */
+ * B = batch (the capacity the workspace was sized for is the caller's business), V = board_size^2, A = policy size. */
 typedef struct aqg_train {
     int32_t board_size, batch, policy_size;
     int32_t step;                 /* Adam step count of THIS update, >= 1 */
     float lr, beta1, beta2, eps;  /* 1e-3 * LambdaLR factor (train_network.py:56-66), 0.9, 0.999, 1e-8 */
     float* params[14]; float* grads[14]; float* adam_m[14]; float* adam_v[14];
     /* workspace */
-    float* x0;                    /* [B*V, 6]   node features */
-    int32_t* ell_idx; float* ell_w;   /* [B*V, 5]  normalised adjacency, ELL: self, U, D, L, R (index -1 = no edge) */
-    float* zbuf;                  /* [B*V, 128] scratch */
     float* h1; float* h2; float* h3;  /* [B*V, 128] post-ReLU activations of the three GCN layers */
-    float* dh;                    /* [B*V, 128] scratch */
+    float* zbuf; float* dh;       /* [B*V, 128] dZ = A_hat dP of layer 3 / layer 2 (the next launch contracts over full rows) */
     float* g; float* dg;          /* [B, 128]   pooled features and their gradient */
     float* hp; float* hv; float* dhp; float* dhv;   /* [B, 64] head hidden layers and gradients */
-    float* lg;                    /* [B, A]     logits; overwritten by d loss / d logits */
+    float* lg;                    /* [B, A]     d loss / d logits */
     float* pol;                   /* [B, A]     softmax policy (the network output) */
-    float* vp; float* val;        /* [B]        pre-tanh value (overwritten by its gradient), tanh value */
+    float* vp; float* val;        /* [B]        d loss / d pre-tanh value; tanh value */
     float* loss;                  /* [B, 2]     per-position policy / value loss terms (their means are the two losses) */
-    float* part;                  /* [64 * (2*128*128 + 128*8 + 3*128) = 2,187,264 floats] partial sums of the row-sliced gradient reductions */
+    float* part;                  /* [B * AQG_TRAIN_PART_FLOATS] per-board partial sums of the trunk's weight and bias gradients */
 } aqg_train;
+#define AQG_TRAIN_PART_FLOATS (2 * 128 * 128 + 128 * 6 + 3 * 128)
 int aqg_gcn_train_step(const aqg_train* t_host, const uint8_t* states72, const float* pi_target, const float* z_target,
                        int mode, void* stream);
+/* A run of consecutive single-process steps (mode 1) with no host work in between -- one epoch of train_network.py:72-95:
+ * step i takes positions order[i*batch .. (i+1)*batch) (int64 indices into the resident arrays states72 [n,72],
+ * pi_target [n,A], z_target [n]; order = NULL means 0..positions-1; the last batch may be short, as the reference's
+ * DataLoader keeps it), t->step is the Adam count of the FIRST step, and every step adds its two batch-mean losses to
+ * loss_sums[2] (device, may be NULL) -- the per-epoch sums train_network.py:89-90 prints. */
+int aqg_gcn_train_steps(const aqg_train* t_host, const uint8_t* states72, const float* pi_target, const float* z_target,
+                        const int64_t* order, long long positions, float* loss_sums, void* stream);
 
 /* ------------------------------------------------------------------ CPU baseline agents (agents.py) -- HOST pointers, host code */
 

@@ -719,6 +719,35 @@ def test_train_adam_steps_vs_torch(dev):
     np.testing.assert_allclose(pol.cpu().numpy(), chk["policy"], atol=2e-6, rtol=1e-3)
 
 
+def test_train_run_epoch_equals_single_steps(dev):
+    """aqg_gcn_train_steps (a whole epoch in one call: on-device gather by the shuffled order, short last batch kept,
+    losses summed on the device) takes bit-identically the steps GNNTrainer.step takes on the same batches -- on the 9x9
+    board and, for the odd tile counts, on 5x5 (25 nodes = 2 row tiles) with its own parameter shapes."""
+    from alphaquoridorgnn_amd.train_network import GNNTrainer
+    from alphaquoridorgnn_amd.pv_network_gnn import GraphPolicyValueNetwork
+    for N, n, batch in ((9, 150, 64), (5, 70, 32)):
+        A = N * N + 2 * (N - 1) ** 2
+        recs, pi, z = _train_batch(n, 21, N=N)
+        order = torch.from_numpy(np.random.RandomState(3).permutation(n))
+        S, P, Z = torch.from_numpy(recs).to(dev), torch.from_numpy(pi).to(dev), torch.from_numpy(z).to(dev)
+        torch.manual_seed(5)
+        ma = GraphPolicyValueNetwork(policy_output_size=A, board_size=N).to(dev)
+        mb = GraphPolicyValueNetwork(policy_output_size=A, board_size=N).to(dev)
+        mb.load_state_dict(ma.state_dict())
+        ta, tb = GNNTrainer(ma, max_batch=batch), GNNTrainer(mb, max_batch=batch)
+        sums = ta.run_epoch(S, P, Z, order, lr=7e-4, pre_shuffle=(N == 9))     # both ways of applying the order
+        ref = torch.zeros(2, device=dev)
+        for i in range(0, n, batch):
+            idx = order[i:i + batch].to(dev)
+            pl, vl = tb.step(S[idx], P[idx], Z[idx], lr=7e-4)
+            ref += torch.stack([pl, vl])
+        assert ta.step_count == tb.step_count == (n + batch - 1) // batch
+        for (k, a), b in zip(ma.state_dict().items(), mb.state_dict().values()):
+            assert torch.equal(a, b), (N, k)
+        np.testing.assert_allclose(sums.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5)
+        assert all(torch.isfinite(v).all() for v in ma.state_dict().values())
+
+
 _DP_WORKER = r'''
 import os, sys
 sys.path.insert(0, os.environ["AQG_REPO"])

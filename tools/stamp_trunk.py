@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 so = "/tmp/libaqgnn_hip_stamp.so"
 src = os.path.join(ROOT, "alphaquoridorgnn_amd", "csrc")
 subprocess.check_call(f"cd {src} && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DAQG_STAMP "
-                      f"legal_mask.hip gcn_forward.hip gcn_train.hip mcts.hip capi.hip host_agents.cpp -o {so} -L/opt/rocm/lib -lrocblas", shell=True)
+                      f"legal_mask.hip gcn_forward.hip gcn_train.hip mcts.hip capi.hip host_agents.cpp -o {so}", shell=True)
 os.environ["AQG_LIB_PATH"] = so
 import torch
 from alphaquoridorgnn_amd import _lib
