@@ -207,12 +207,13 @@ def main():
     # every variant is timed three times in interleaved order and its best time kept: a single pass right after the pools
     # were freed under-reported the exact-f32 kernel by 3.4x in the round-1 driver run (4.96 M vs 17 M boards/s here)
     names = (("f32_mfma_exact", 1), ("f16_split_mm_8wave_x2", 6), ("f16_split_mm_4wave_x2", 5))
-    variants = {n: {"ms": float("inf")} for n, _ in names}
+    variants = {n: {"ms_samples": []} for n, _ in names}
     for rep in range(3):
         for name, v in names:
             _lib.set_option("trunk_variant", v)
-            variants[name]["ms"] = min(variants[name]["ms"], time_ms(fwd, 60, warmup=10))
+            variants[name]["ms_samples"].append(time_ms(fwd, 60, warmup=10))
     for name in variants:
+        variants[name]["ms"] = min(variants[name]["ms_samples"])
         variants[name]["boards_per_s"] = B / (variants[name]["ms"] * 1e-3)
     _lib.set_option("trunk_variant", 3)
     fwd_ms = min(time_ms(fwd, 200, warmup=20) for _ in range(2))      # default variant, after the clocks have settled on this workload

@@ -15,11 +15,11 @@ from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
 from tools.microbench import synth_states
 dev = _lib.require_gpu("cuda:0"); lib = _lib.load()
 model = GNNNetwork().to(dev).eval(); pk = model.packed_weights(dev)
-B = 65536
+B = int(os.environ.get("AQG_B", "65536"))
 st = synth_states(B)
 names = ["setup", "L1a gather6", "L1b 6->128", "L2 mfma", "L2 stripe gather", "L3 mfma", "L3 gather+pool", "loop top", "wait vmcnt before L1b", "wait vmcnt before L3", "-", "-", "-", "-", "-", "-"]
-names5 = ["setup (to barrier)", "L1 final barrier", "L2 mfma", "L2 final barrier", "L3 mfma", "L3 store/pool + raw + barrier", "-", "loop top (w1f+Bf load issue)", "L1 X0 mfma", "L1 adj_matmul", "L1 adj_store", "L2 Bf3 load issue", "L2 adj_matmul", "L2 mid barrier", "L2 adj_store", "L3 adj_matmul"]
-for v, grid in ((3, 256), (3, 512), (4, 512)):
+names5 = ["setup (record wait, decode, adjacency fragments, barrier)", "barrier after layer-1 aggregation", "layer-2 linear (MFMA + split)", "barrier after layer-2 aggregation", "layer-3 linear (MFMA + split)", "layer-3 aggregation + pool + store (+ end barrier)", "-", "loop top (w1f request)", "layer-1 X0 W1 MFMA + split", "layer-1 aggregation + plane stores", "-", "-", "W3 fragment request + next record", "barrier: planes read by everybody", "layer-2 aggregation + plane stores", "-"]
+for v, grid in ((6, 512), (5, 512)):
     _lib.set_option("trunk_variant", v); _lib.set_option("trunk_grid", grid)
     pooled = torch.zeros((B + 1, 128), device=dev)
     for _ in range(3):
@@ -29,4 +29,4 @@ for v, grid in ((3, 256), (3, 512), (4, 512)):
     n = raw[16]; tot = sum(raw[:16])
     print(f"variant {v} grid {grid}: boards by WG0 = {n}, cycles/board (s_memtime @100MHz units?) = {tot / max(n,1):.1f}")
     for nm, c in zip(names5 if v >= 3 else names, raw[:16]):
-        print(f"   {nm:18s} {c / max(n,1):10.1f}  {100.0 * c / tot:5.1f}%")
+        print(f"   {nm:62s} {c / max(n,1):10.1f}  {100.0 * c / tot:5.1f}%")
