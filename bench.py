@@ -265,6 +265,31 @@ def main():
                               "~130 legal moves); the lock-step generation of the headline value keeps all games in the same phase"}
         del er
         torch.cuda.empty_cache()
+        # the same comparison where refill is meant to pay: SHORT games of very different lengths (fake evaluator with a strong
+        # forward bias: pawns race to the goal), lock-step generations vs refilled slots, same slots, same number of games
+        def short_games(quota_mult, generations):
+            es = MultiSetSelfPlay(None, num_games=args.games, sims=args.sims, num_sets=args.sets, seed=9, quota=quota_mult * args.games,
+                                  evaluator="fake", fake_bias=40)
+            es.move(); es.sync(); torch.cuda.synchronize()
+            fin = pos = ev = plies = 0
+            t2 = time.time()
+            for _ in range(generations):
+                es.reset()
+                c2 = es.play_generation()
+                fin += c2["finished"]; ev += c2["leaf_evals"]
+                pos += int(es.history_tensors()[0].shape[0])
+                plies += max(e2.moves_done for e2 in es.sets)
+            torch.cuda.synchronize()
+            d2 = time.time() - t2
+            return {"games_per_s": fin / d2, "leaf_evals_per_s": ev / d2, "games": fin, "mean_plies": pos / max(fin, 1),
+                    "slot_utilisation": pos / max(1.0, float(args.games) * plies)}
+        sg_lock, sg_refill = short_games(1, 3), short_games(3, 1)
+        refill_leg["short_games"] = {"workload": f"fake evaluator, forward bias 40, {args.sims} sims/move: 3 x {args.games} games on {args.games} slots",
+                                     "lockstep": sg_lock, "refill": sg_refill,
+                                     "refill_over_lockstep_games_per_s": sg_refill["games_per_s"] / sg_lock["games_per_s"],
+                                     "games_per_leaf_eval_refill_over_lockstep": (sg_refill["games_per_s"] / sg_refill["leaf_evals_per_s"]) /
+                                                                                 (sg_lock["games_per_s"] / sg_lock["leaf_evals_per_s"])}
+        torch.cuda.empty_cache()
         # ---- next-row leg: train_network.py's optimisation step on the GNN, batch 128 (train_network.py:15)
         from alphaquoridorgnn_amd.train_network import GNNTrainer, BATCH_SIZE
         tr_model = GNNNetwork().to(dev)
