@@ -1585,6 +1585,12 @@ static hipEvent_t prof_event() {
     return g_prof_events[g_prof_used++];
 }
 
+// one event on `st`; units >= 0 marks the BEGIN of a bracket and adds to the unit counter (boards / games), < 0 marks its end
+void profile_mark(hipStream_t st, long long units) {
+    (void)hipEventRecord(prof_event(), st);
+    if (units > 0) g_prof_boards += units;
+}
+
 int profile_collect(double* total_ms, long long* launches, long long* boards, int reset) {
     if (g_prof_used) {
         for (size_t i = 0; i + 1 < g_prof_used; i += 2) {
@@ -1615,7 +1621,7 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     // persistent grid: 256 CUs x resident workgroups per CU, grid-stride over boards
     const int variant = (flags & 1) ? (g_trunk_variant == 0 ? 0 : 1) : g_trunk_variant;   // AQG_GNN_EXACT_F32
     bool fused = false;
-    if (g_profile_trunk) { (void)hipEventRecord(prof_event(), st); g_prof_boards += B; }
+    if (g_profile_trunk == 1) { (void)hipEventRecord(prof_event(), st); g_prof_boards += B; }
     if (variant == 0) {
         int grid = B < 256 ? B : 256;
         hipLaunchKernelGGL((gcn_trunk_boards_kernel<true, 1>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
@@ -1641,7 +1647,7 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
             hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0);
         }
     }
-    if (g_profile_trunk) (void)hipEventRecord(prof_event(), st);
+    if (g_profile_trunk == 1) (void)hipEventRecord(prof_event(), st);
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;
     if (fused) return 0;                                        // the trunk workgroups did their boards' heads themselves
     if (!logits && !policy && !value_pre && !value) return 0;   // trunk only (bench: time the dominant kernel alone)

@@ -36,6 +36,7 @@ int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, con
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
                                   float* value, const uint8_t* active, int flags, hipStream_t st);
 extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, g_profile_trunk, g_fuse_heads;
+void profile_mark(hipStream_t st, long long units);
 int g_use_graph = 1;       // aqg_set_option("use_graph", 0) forces plain launches
 
 __device__ __forceinline__ int wave_sum_i(int v) {
@@ -751,8 +752,10 @@ __global__ __launch_bounds__(256) void engine_step_kernel(aqg_engine e, int do_e
 template <int N>
 static void launch_step(const aqg_engine& e, int do_expand, int do_select, hipStream_t st) {
     const dim3 grid((e.num_games + 3) / 4), block(256);
+    if (g_profile_trunk == 2) profile_mark(st, e.num_games);       // measurement mode 2: the event pairs bracket the step launches
     if (g_step_variant == 1) hipLaunchKernelGGL(engine_step_fast_kernel<N>, grid, block, 0, st, e, do_expand, do_select, g_step_fast_depth);
     else hipLaunchKernelGGL(engine_step_kernel<N>, grid, block, 0, st, e, do_expand, do_select);
+    if (g_profile_trunk == 2) profile_mark(st, -1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -225,22 +225,28 @@ def main():
         step_leg = {"kernel": "engine_step_fast_kernel<9> (backup + expansion of the previous simulation, PUCT descent, legal moves of the leaf)",
                     "bound": "latency", "us_per_launch": {}, "game_steps_per_s": {}, "waves_per_simd": {}}
         for G in (512, 4096):
-            # the fake evaluator (uniform priors, value 0) leaves the step kernel as the only per-simulation launch: a move is
-            # one graph replay of sims back-to-back step launches, so move time / sims = the launch-to-launch period
-            e1 = BatchedSelfPlay(None, num_games=G, sims=args.sims, evaluator="fake", fake_bias=0, seed=5, record_history=False)
-            for _ in range(20):
-                e1.move()                                     # plies 0-19: openings (up to 131 legal moves per node)
+            # the real loop, one game set alone on the GPU with plain launches, HIP event pairs around the step launches
+            # (aqg_set_option("profile_trunk", 2)): plies 24-31 of a GNN-evaluated generation
+            e1 = BatchedSelfPlay(model, num_games=G, sims=args.sims, seed=5, record_history=False)
+            for _ in range(24):
+                e1.move()
             torch.cuda.synchronize()
-            t1 = time.time()
-            for _ in range(40):
-                e1.move()                                     # plies 20-59: the middle game, where most of a generation's time goes
-            torch.cuda.synchronize()
-            us = (time.time() - t1) / (40 * args.sims) * 1e6
+            _lib.profile_collect(reset=True)
+            _lib.set_option("profile_trunk", 2)
+            for _ in range(8):
+                e1.move()
+                torch.cuda.synchronize()
+                _lib.profile_collect()
+            _lib.set_option("profile_trunk", 0)
+            ms, n, _ = _lib.profile_collect(reset=True)
+            us = ms / max(n, 1) * 1e3
             step_leg["us_per_launch"][str(G)] = us
+            step_leg["launches_timed"] = int(n)
             step_leg["game_steps_per_s"][str(G)] = G / (us * 1e-6)
             step_leg["waves_per_simd"][str(G)] = G / 1024.0
             del e1
-        step_leg["note"] = ("launch-to-launch period over plies 20-59 of fake-evaluator games (40 moves x sims launches, hipGraph replay); one "
+        step_leg["note"] = ("HIP event pairs around every step launch of plies 24-31 of GNN-evaluated games (the pair also brackets the "
+                            "dispatch gap, ~3 us: rocprofv3 on the bench command gives 14.4 us at 512 games, profiles/r02_bench_kernel_stats_default_4sets.csv); one "
                             "wavefront per game; per simulation ONE round of dependent loads (root record + root children + the previous "
                             "leaf's policy, everything else patched in registers) plus one per tree level below the root; no bandwidth or "
                             "FLOP roof applies (PMC: profiles/r02_pmc_summary.csv) -- the figure of merit is us per launch, which the "

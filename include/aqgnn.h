@@ -34,14 +34,16 @@ extern "C" {
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
 /* tuning knobs: "trunk_variant" 0/1 = exact f32-input MFMA with 1/2 workgroups per CU, 3 = all-MFMA fp16 split trunk
- * (hi*hi + hi*lo + lo*hi: fp32-equivalent products; default, form chosen per launch size), 4 / 5 / 6 = force the
- * 4-wave x 3-per-CU / 4-wave x 2-per-CU / 8-wave x 2-per-CU form;
+ * (hi*hi + hi*lo + lo*hi: fp32-equivalent products; default = the 8-wave x 2-per-CU form, also selected by 6), 4 / 5 = the
+ * 4-wave x 2-per-CU form; "step_variant" 1/0 = one-load-round MCTS step / round-1 step, "step_fast_depth" = tree depth at which
+ * the fast step hands over to memory mode; "fuse_heads" 1 = heads inside the trunk workgroup (measured slower, default 0);
  * "trunk_phase_delay" = start offset of the second- / third-resident workgroups in units of 64 cycles, applied to
  * launches of at least "trunk_delay_min_boards" boards; "use_graph" 0/1 = replay
- * a move's 3*sims+2 launches as one captured hipGraph when the stream is capturable (default 1); "profile_trunk" 0/1 = event pairs around trunk launches */
+ * a move's 3*sims+2 launches as one captured hipGraph when the stream is capturable (default 1); "profile_trunk" 0/1/2 = no event pairs / around trunk launches / around MCTS step launches */
 int aqg_set_option(const char* name, int value);
 /* Measurement aid (bench.py): with option "profile_trunk" = 1 a HIP event pair is recorded around every launch of the
- * dominant kernel (the GCN trunk) on its launch stream.  This call waits for the last recorded event, accumulates
+ * dominant kernel (the GCN trunk) on its launch stream; = 2 brackets the MCTS step kernel's launches instead (`boards` then
+ * counts games).  This call waits for the last recorded event, accumulates
  * the elapsed times and returns the running totals (HOST pointers; `boards` = sum of launch batch sizes incl.
  * masked-out rows); reset != 0 clears the totals.  It is the only entry point that blocks the host. */
 int aqg_profile_collect(double* total_ms_host, long long* launches_host, long long* boards_host, int reset);
