@@ -6,6 +6,7 @@ namespace aqg {
 thread_local char g_err[512] = "";
 extern int g_trunk_variant;
 extern int g_profile_trunk;
+extern int g_train_fused;
 extern int g_trunk_grid;
 extern int g_trunk_phase_delay;
 extern int g_trunk_delay_min_boards;
@@ -63,6 +64,7 @@ int aqg_set_option(const char* name, int value) {
     if (name && !strcmp(name, "step_variant")) { g_step_variant = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "step_fast_depth")) { if (value < 0 || value > 61) return fail("step_fast_depth must be 0..61"); g_step_fast_depth = value; return 0; }
     if (name && !strcmp(name, "fuse_heads")) { g_fuse_heads = value ? 1 : 0; return 0; }
+    if (name && !strcmp(name, "train_fused")) { g_train_fused = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "use_graph")) { g_use_graph = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "profile_trunk")) { g_profile_trunk = (value == 1 || value == 2) ? value : 0; return 0; }   // 1 = trunk launches, 2 = step launches
     return fail("unknown option", name ? name : "(null)");

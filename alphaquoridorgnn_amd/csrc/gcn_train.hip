@@ -9,23 +9,27 @@
 //   backward  dP = dH' (.) [H' > 0];  db = colsum dP;  dZ = A_hat dP (A_hat symmetric);  dW = dZ^T H;  dH = dZ W
 //   update    torch.optim.Adam (lr, betas, eps; bias-corrected; no weight decay, no amsgrad)
 //
-// The batch is 128 positions (train_network.py:15) = 10,368 graph nodes and 2.1 GFLOP per step: a latency-bound,
-// L2-resident job, so the step is SEVEN launches, every contraction over the node rows on the f32 matrix pipe
-// (v_mfma_f32_16x16x4_f32: exact f32 products, which the 2e-5 gradient parity against fp64 autograd needs):
+// The batch is 128 positions (train_network.py:15) = 10,368 graph nodes and 2.2 GFLOP per step.  Every contraction over the
+// node rows runs on the f32 matrix pipe (v_mfma_f32_16x16x4_f32: exact f32 products, which the 2e-5 gradient parity against
+// fp64 autograd needs).  Two forms of the step (aqg_set_option("train_fused")):
 //
-//   fwd12   (board, column half)  features + graph from the record; layer 1 (K = 6, both halves redundantly), layer 2 half
-//   fwd3    (board, column half)  layer 3 half + the mean pool of that half
-//   heads   (board)               both heads, the two losses, and the head gradients back to dg
-//   bwd<3>  (board, column half)  dP3, db3, dZ3 = A_hat dP3, dW3 = dZ3^T H2 (per-board partial)
-//   bwd<2>  (board, column half)  dH2 = dZ3 W3 (half of the columns), dP2, db2, dZ2, dW2 partial
-//   bwd<1>  (board, column half)  dH1 = dZ2 W2, dP1, db1, dZ1, dW1 partial
+//   fused (default): train_board_kernel -- ONE 8-wave workgroup per position does forward, heads + losses and backward; only
+//     the per-board partial gradients leave the CU -- then train_final_kernel.
+//   six launches + final: two workgroups per board split the 128 feature columns (all 256 CUs busy at batch 128) and exchange
+//     full rows through memory between launches:
+//       fwd12   (board, column half)  features + graph from the record; layer 1 (K = 6, both halves redundantly), layer 2 half
+//       fwd3    (board, column half)  layer 3 half + the mean pool of that half
+//       heads   (board)               both heads, the two losses, and the head gradients back to dg
+//       bwd<3>  (board, column half)  dP3, db3, dZ3 = A_hat dP3, dW3 = dZ3^T H2 (per-board partial)
+//       bwd<2>  (board, column half)  dH2 = dZ3 W3 (half of the columns), dP2, db2, dZ2, dW2 partial
+//       bwd<1>  (board, column half)  dH1 = dZ2 W2, dP1, db1, dZ1, dW1 partial
+//     The column split is consistent through the chain: the aggregation is per column, and each contraction takes FULL rows of
+//     its input (written by the previous launch) and produces one column half.
 //   final   (parameter element)   sums the per-board partials in a fixed order, forms the head weight gradients as
 //                                 batch dot products, writes the gradient and applies Adam to that element
 //
-// A board's 81 node rows never leave its workgroup (the aggregation needs all of them); splitting the 128 feature
-// columns over two workgroups fills all 256 CUs at batch 128.  The column split is consistent through the chain: the
-// aggregation is per column, and each contraction takes FULL rows of its input (written by the previous launch) and
-// produces one column half.  No atomics anywhere: results are run-to-run identical.
+// A board's 81 node rows never leave its workgroup (the aggregation needs all of them).  No atomics anywhere: results are
+// run-to-run identical.
 #include "aqg_common.hpp"
 #include "../../include/aqgnn.h"
 
@@ -44,7 +48,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Diagnostic build only (-DAQG_STAMP, tools/stamp_train.py; never shipped): thread 0 of workgroup 0 adds the cycles between
 // consecutive phase marks of kernel k to g_train_stamp[k][phase].
 #ifdef AQG_STAMP
-__device__ unsigned long long g_train_stamp[8][8];
+__device__ unsigned long long g_train_stamp[10][16];
 #define TS_DECL unsigned long long ts_prev = __builtin_readcyclecounter();
 #define TS(k, i) { const unsigned long long ts_now = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) g_train_stamp[k][i] += ts_now - ts_prev; ts_prev = ts_now; }
 #else
@@ -151,6 +155,45 @@ __device__ __forceinline__ void mfma_rows(f32x4 (&acc)[RT], const float* As, con
     }
 }
 
+// The same contraction with the B operand held in registers (the fused per-board kernel: its LDS is full of activations):
+// bw[ks] = W[(4 ks + q) * sk + col * sc], 32 strided dwords per lane, requested one phase ahead of their use.
+__device__ __forceinline__ void load_bfrag(float (&bw)[32], const float* __restrict__ W, int sk, int sc, int col, int q) {
+    const float* p = W + (size_t)col * sc + (size_t)q * sk;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) bw[ks] = p[(size_t)4 * ks * sk];
+}
+// Forward form (B[k][c] = W[c][k], a row of W per output column): 16-byte loads, lane (c, q) holds W[c][16 j + 4 q .. + 3], so the
+// contraction index is enumerated as k = 16 j + 4 q + e and the A operand comes by ds_read_b128 (4 k values per lane; with
+// the 132-float row stride the 16 rows of a quarter wave fall into 16 different 16-byte bank groups).  A quarter of the
+// address-unit work of the dword form (16 segments per instruction either way, 8 instructions instead of 32).
+__device__ __forceinline__ void load_bfrag4(f32x4 (&bv)[8], const float* __restrict__ W, int col, int q) {
+    const float* p = W + (size_t)col * TH + 4 * q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = ld4(p + 16 * j);
+}
+template <int RT>
+__device__ __forceinline__ void mfma_rows_reg4(f32x4 (&acc)[RT], const float* As, const f32x4 (&bv)[8], int r16, int q) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f32x4 a[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[rt] = ld4(As + (16 * rt + r16) * SA + 16 * j + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma4(a[rt][e], bv[j][e], acc[rt]);
+        }
+    }
+}
+template <int RT>
+__device__ __forceinline__ void mfma_rows_reg(f32x4 (&acc)[RT], const float* As, const float (&bw)[32], int r16, int q) {
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma4(As[(16 * rt + r16) * SA + 4 * ks + q], bw[ks], acc[rt]);
+    }
+}
+
 // accumulator tiles -> LDS image [rows][64] (stride SZ); this wave's 16 columns start at 16 * wave
 template <int RT>
 __device__ __forceinline__ void store_acc(float* Zs, const f32x4 (&acc)[RT], int wave, int r16, int q) {
@@ -163,20 +206,20 @@ __device__ __forceinline__ void store_acc(float* Zs, const f32x4 (&acc)[RT], int
 
 // rows [0, V) x 128 floats of a global [.][128] array -> LDS image with row stride S, rows [V, VZ) zero-filled.  Two
 // halves so that a caller can put other work between the issue of the loads and the LDS writes.
-template <int V, int VZ> struct RowTile {
-    static constexpr int IT = (VZ * 32 + 255) / 256;
+template <int V, int VZ, int NT = 256> struct RowTile {
+    static constexpr int IT = (VZ * 32 + NT - 1) / NT;
     f32x4 v[IT];
     __device__ __forceinline__ void issue(const float* __restrict__ src, int t) {
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
-            const int i = t + 256 * k, n = i >> 5, c4 = (i & 31) * 4;
+            const int i = t + NT * k, n = i >> 5, c4 = (i & 31) * 4;
             v[k] = n < V ? ld4(src + (size_t)n * TH + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     template <int S> __device__ __forceinline__ void land(float* dst, int t) const {
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
-            const int i = t + 256 * k, n = i >> 5, c4 = (i & 31) * 4;
+            const int i = t + NT * k, n = i >> 5, c4 = (i & 31) * 4;
             if (n < VZ) st4(dst + n * S + c4, v[k]);
         }
     }
@@ -346,71 +389,96 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
-__global__ __launch_bounds__(256) void train_heads_kernel(const float* __restrict__ g, HeadParams Pm,
-                                                          const float* __restrict__ pi_all, const float* __restrict__ z_all,
-                                                          const int64_t* __restrict__ order, int first, int A, int B,
-                                                          float* __restrict__ hp, float* __restrict__ hv, float* __restrict__ lg,
-                                                          float* __restrict__ pol, float* __restrict__ vp, float* __restrict__ val,
-                                                          float* __restrict__ loss, float* __restrict__ dhp, float* __restrict__ dhv,
-                                                          float* __restrict__ dg) {
-    __shared__ float gs[TH], hs[TH], dhs[TH], dl[256], red[2][4][2], part[4 * TH];
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+struct HeadsSmem { float gs[TH], hs[TH], dhs[TH], dl[256], red[2][8][2], part[4 * TH]; };
+// One position's heads, losses and head gradients by a workgroup of NW wavefronts (the first four do the work; all take part
+// in the barriers).  `sm.gs` = the pooled features if g == nullptr (the fused kernel has them in LDS already); on return
+// sm.part[0..127] + sm.part[128..255] = dg, also stored to dg_out if that is not null.
+template <int NW>
+__device__ __forceinline__ void heads_board(HeadsSmem& sm, int b, const float* __restrict__ g, const HeadParams& Pm,
+                                            const float* __restrict__ pi_all, const float* __restrict__ z_all,
+                                            const int64_t* __restrict__ order, int first, int A, int B,
+                                            float* __restrict__ hp, float* __restrict__ hv, float* __restrict__ lg,
+                                            float* __restrict__ pol, float* __restrict__ vp, float* __restrict__ val,
+                                            float* __restrict__ loss, float* __restrict__ dhp, float* __restrict__ dhv,
+                                            float* __restrict__ dg) {
+    float (&gs)[TH] = sm.gs; float (&hs)[TH] = sm.hs; float (&dhs)[TH] = sm.dhs; float (&dl)[256] = sm.dl;
+    float (&red)[2][8][2] = sm.red; float (&part)[4 * TH] = sm.part;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool worker = t < 256;
     const float *Wp1 = Pm.p[0], *bp1 = Pm.p[1], *Wp2 = Pm.p[2], *bp2 = Pm.p[3], *Wv1 = Pm.p[4], *bv1 = Pm.p[5], *Wv2 = Pm.p[6], *bv2 = Pm.p[7];
     const size_t rec = record_of(order, first, b);
     int flip = 0;                                 // two exchange rows, used alternately: one barrier per reduction
     auto block_sum2 = [&](float& x, float& y) {
         x = wave_sum(x); y = wave_sum(y);
-        if (lane == 0) { red[flip][wave][0] = x; red[flip][wave][1] = y; }
+        if (lane == 0 && worker) { red[flip][wave][0] = x; red[flip][wave][1] = y; }
         __syncthreads();
-        x = (red[flip][0][0] + red[flip][1][0]) + (red[flip][2][0] + red[flip][3][0]);
+        x = (red[flip][0][0] + red[flip][1][0]) + (red[flip][2][0] + red[flip][3][0]);      // waves 4.. hold zeros / -inf: not read
         y = (red[flip][0][1] + red[flip][1][1]) + (red[flip][2][1] + red[flip][3][1]);
         flip ^= 1;
     };
-    auto block_max = [&](float v) { v = wave_max(v); if (lane == 0) red[flip][wave][0] = v; __syncthreads(); const float r = fmaxf(fmaxf(red[flip][0][0], red[flip][1][0]), fmaxf(red[flip][2][0], red[flip][3][0])); flip ^= 1; return r; };
+    auto block_max = [&](float v) { v = wave_max(v); if (lane == 0 && worker) red[flip][wave][0] = v; __syncthreads(); const float r = fmaxf(fmaxf(red[flip][0][0], red[flip][1][0]), fmaxf(red[flip][2][0], red[flip][3][0])); flip ^= 1; return r; };
     TS_DECL
-    // every weight this workgroup multiplies by is requested up front (one wave per SIMD: the registers are there)
+    constexpr int HEADS_TS = NW == 4 ? 2 : 7;
+    (void)HEADS_TS;
+    // Every weight this workgroup multiplies by is requested up front, and by COALESCED loads: a wave takes whole rows of the
+    // two first-layer matrices (512 B: two columns per lane) and of policy_head.2 (256 B: one column per lane) and reduces
+    // each row's products with a DPP wave sum.  (One thread per output row -- 64 different rows per load instruction -- spent
+    // 14 k cycles in the address unit before the first multiply.)
     const bool on = t < A;
-    const int ho = t >> 1, kh = (t & 1) * HH, hj = ho & 63;       // hidden layers: two threads per output, 64 terms each
-    f32x4 wh[16], wl[16];
-    {
-        const float* wr = (ho < HH ? Wp1 : Wv1) + (size_t)hj * TH + kh;
+    constexpr int HROWS = TH / NW;                                  // hidden units per wave (rows w, w + NW, ...)
+    constexpr int LROWS = (256 + NW - 1) / NW;                      // logits per wave
+    float wh0[HROWS], wh1[HROWS], wl[LROWS];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) wh[k] = ld4(wr + 4 * k);
-        const float* wq = Wp2 + (size_t)(on ? t : 0) * HH;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) wl[k] = ld4(wq + 4 * k);
+    for (int i = 0; i < HROWS; ++i) {
+        const int o = wave + NW * i;
+        const float* wr = (o < HH ? Wp1 + (size_t)o * TH : Wv1 + (size_t)(o - HH) * TH) + 2 * lane;
+        wh0[i] = wr[0]; wh1[i] = wr[1];
     }
-    const int per = (A + 3) / 4, a0 = wave * per;                 // d loss / d policy hidden layer: A terms dealt over the 4 waves
-    float wd[64];
 #pragma unroll
-    for (int u = 0; u < 64; ++u) wd[u] = (u < per && a0 + u < A) ? Wp2[(size_t)(a0 + u) * HH + lane] : 0.f;
+    for (int i = 0; i < LROWS; ++i) {
+        const int a = wave + NW * i;
+        wl[i] = a < A ? Wp2[(size_t)a * HH + lane] : 0.f;
+    }
+    constexpr int DROWS = 256 / NW;                                    // d loss / d policy hidden layer: the A terms dealt over the waves
+    const int per = (A + NW - 1) / NW, a0 = wave * per;
+    float wd[DROWS];
+#pragma unroll
+    for (int u = 0; u < DROWS; ++u) wd[u] = (u < per && a0 + u < A) ? Wp2[(size_t)(a0 + u) * HH + lane] : 0.f;
     const float tgt = on ? pi_all[rec * A + t] : 0.f;
     const float zt = z_all[rec];
-    const float hb = (ho < HH ? bp1 : bv1)[hj], lb = on ? bp2[t] : 0.f, wv2 = Wv2[lane], bv = bv2[0];
-    if (t < TH) gs[t] = g[(size_t)b * TH + t];
+    const float lb = on ? bp2[t] : 0.f, wv2 = Wv2[lane], bv = bv2[0];
+    const float hbias = lane < HROWS ? ((wave + NW * lane) < HH ? bp1[wave + NW * lane] : bv1[wave + NW * lane - HH]) : 0.f;
+    if (g && t < TH) gs[t] = g[(size_t)b * TH + t];
     __syncthreads();
-    TS(2, 0)
+    TS(HEADS_TS, 0)
     {   // hidden layers: hs[0..63] policy, hs[64..127] value
-        float s = 0.f;
+        const float g0 = gs[2 * lane], g1 = gs[2 * lane + 1];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { s = fmaf(wh[k].x, gs[kh + 4 * k], s); s = fmaf(wh[k].y, gs[kh + 4 * k + 1], s); s = fmaf(wh[k].z, gs[kh + 4 * k + 2], s); s = fmaf(wh[k].w, gs[kh + 4 * k + 3], s); }
-        s += __shfl_xor(s, 1);
-        s = fmaxf(s + hb, 0.f);
-        if ((t & 1) == 0) {
-            hs[ho] = s;
-            (ho < HH ? hp : hv)[(size_t)b * HH + hj] = s;
+        for (int i = 0; i < HROWS; ++i) {
+            const int o = wave + NW * i;
+            float s = wave_sum(fmaf(wh0[i], g0, wh1[i] * g1));
+            s = fmaxf(s + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hbias), i)), 0.f);
+            if (lane == 0) {
+                hs[o] = s;
+                (o < HH ? hp : hv)[(size_t)b * HH + (o & 63)] = s;
+            }
         }
     }
     __syncthreads();
-    TS(2, 1)
-    float l = -INFINITY;
-    if (on) {
-        float s = lb;
+    TS(HEADS_TS, 1)
+    {
+        const float h = hs[lane];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { s = fmaf(wl[k].x, hs[4 * k], s); s = fmaf(wl[k].y, hs[4 * k + 1], s); s = fmaf(wl[k].z, hs[4 * k + 2], s); s = fmaf(wl[k].w, hs[4 * k + 3], s); }
-        l = s;
+        for (int i = 0; i < LROWS; ++i) {
+            const int a = wave + NW * i;
+            const float s = wave_sum(wl[i] * h);
+            if (lane == 0 && a < A) dl[a] = s;                       // (dl is reused for d loss / d logits below)
+        }
     }
-    TS(2, 2)
+    __syncthreads();
+    const float l = on ? dl[t] + lb : -INFINITY;
+    __syncthreads();                                                 // everybody holds its logit before dl is overwritten
+    TS(HEADS_TS, 2)
     const float m = block_max(l);
     const float e = on ? expf(l - m) : 0.f;
     float se = e, tsum = tgt;
@@ -424,7 +492,7 @@ __global__ __launch_bounds__(256) void train_heads_kernel(const float* __restric
     float lp = on ? -tgt * (p - logf(s2)) : 0.f, dot = dpol * p;
     block_sum2(lp, dot);
     const float dlogit = on ? p * (dpol - dot) : 0.f;            // back through the first softmax
-    dl[t] = dlogit;
+    if (worker) dl[t] = dlogit;
     if (on) {
         pol[(size_t)b * A + t] = p;
         lg[(size_t)b * A + t] = dlogit;
@@ -439,35 +507,50 @@ __global__ __launch_bounds__(256) void train_heads_kernel(const float* __restric
         loss[2 * b + 1] = dv * dv;
     }
     __syncthreads();
-    TS(2, 3)
+    TS(HEADS_TS, 3)
     {
         float s = 0.f;
 #pragma unroll
-        for (int u = 0; u < 64; ++u) s = fmaf(dl[min(a0 + u, 255)], wd[u], s);
+        for (int u = 0; u < DROWS; ++u) s = fmaf(dl[min(a0 + u, 255)], wd[u], s);
         part[wave * HH + lane] = s;
     }
     __syncthreads();
-    TS(2, 4)
+    TS(HEADS_TS, 4)
     if (t < TH) {
         const int j = t & 63;
-        float s = t < HH ? (part[j] + part[HH + j]) + (part[2 * HH + j] + part[3 * HH + j]) : dvp * Wv2[j];
+        float s;
+        if (t < HH) {
+            s = (part[j] + part[HH + j]) + (part[2 * HH + j] + part[3 * HH + j]);
+            if (NW == 8) s += (part[4 * HH + j] + part[5 * HH + j]) + (part[6 * HH + j] + part[7 * HH + j]);
+        } else s = dvp * Wv2[j];
         if (!(hs[t] > 0.f)) s = 0.f;
         dhs[t] = s;
         (t < HH ? dhp : dhv)[(size_t)b * HH + j] = s;
     }
     __syncthreads();
-    TS(2, 5)
+    TS(HEADS_TS, 5)
     {   // dg = dhp W_p1 + dhv W_v1: threads 0..127 the policy part, 128..255 the value part
-        const int k = t & 127, hsel = t >> 7;
+        const int k = t & 127, hsel = (t >> 7) & 1;
         const float* W = hsel ? Wv1 : Wp1;
         float s = 0.f;
 #pragma unroll 16
         for (int j = 0; j < HH; ++j) s = fmaf(dhs[hsel * HH + j], W[(size_t)j * TH + k], s);
-        part[hsel * TH + k] = s;
+        if (worker) part[hsel * TH + k] = s;
     }
     __syncthreads();
-    TS(2, 6)
-    if (t < TH) dg[(size_t)b * TH + t] = part[t] + part[TH + t];
+    TS(HEADS_TS, 6)
+    if (dg && t < TH) dg[(size_t)b * TH + t] = part[t] + part[TH + t];
+}
+
+__global__ __launch_bounds__(256) void train_heads_kernel(const float* __restrict__ g, HeadParams Pm,
+                                                          const float* __restrict__ pi_all, const float* __restrict__ z_all,
+                                                          const int64_t* __restrict__ order, int first, int A, int B,
+                                                          float* __restrict__ hp, float* __restrict__ hv, float* __restrict__ lg,
+                                                          float* __restrict__ pol, float* __restrict__ vp, float* __restrict__ val,
+                                                          float* __restrict__ loss, float* __restrict__ dhp, float* __restrict__ dhv,
+                                                          float* __restrict__ dg) {
+    __shared__ HeadsSmem sm;
+    heads_board<4>(sm, blockIdx.x, g, Pm, pi_all, z_all, order, first, A, B, hp, hv, lg, pol, vp, val, loss, dhp, dhv, dg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -594,6 +677,236 @@ __global__ __launch_bounds__(256) void train_bwd_kernel(const uint8_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// The whole forward + backward of ONE position in one workgroup (8 wavefronts; wave w owns feature columns 16 w .. 16 w + 15,
+// and rows 16 w .. of the weight gradients).  Nothing but the per-board partial gradients leaves the CU: the activations H1,
+// H2 go to memory once and come back through the L2 of the same XCD, H3 never leaves LDS.  grid = B.
+// LDS: Hs (A operand: H_l, then dZ_l), Zs (accumulator images; the heads' scratch), Hb (H_{l-1} as the B operand of the
+// weight gradient and as the ReLU mask of the next layer down).
+// ---------------------------------------------------------------------------------------------
+struct TrunkParams { const float* p[6]; };       // state_dict tensors 0..5
+template <int N>
+__global__ __launch_bounds__(512) void train_board_kernel(const uint8_t* __restrict__ states72, const int64_t* __restrict__ order, int first,
+                                                          TrunkParams tp, HeadParams hpm, const float* __restrict__ pi_all,
+                                                          const float* __restrict__ z_all, int A, int B,
+                                                          float* __restrict__ h1, float* __restrict__ h2, float* __restrict__ g_out,
+                                                          float* __restrict__ hp, float* __restrict__ hv, float* __restrict__ lg,
+                                                          float* __restrict__ pol, float* __restrict__ vp, float* __restrict__ val,
+                                                          float* __restrict__ loss, float* __restrict__ dhp, float* __restrict__ dhv,
+                                                          float* __restrict__ part_dW3, float* __restrict__ part_dW2,
+                                                          float* __restrict__ part_dW1, float* __restrict__ part_db) {
+    constexpr int V = N * N, RT = (V + 15) / 16, VK = (V + 3) / 4 * 4, NIT = (V + 15) / 16;
+    __shared__ float Hs[96 * SA];
+    __shared__ float Zs[96 * SA];
+    __shared__ float Hb[84 * SB];
+    __shared__ float cs[4 * TH];
+    __shared__ BoardGraph gr;
+    HeadsSmem& hsm = *reinterpret_cast<HeadsSmem*>(Zs);
+    static_assert(sizeof(HeadsSmem) <= sizeof(float) * 96 * SA && 16 * TH <= 84 * SB, "scratch aliases");
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6, q = lane >> 4, r16 = lane & 15;
+    const int col = 16 * wave + r16;
+    const int c4 = (t & 31) * 4, rg = t >> 5;                       // aggregation mapping: 32 float4 per row x 16 row groups
+    const float *W1 = tp.p[0], *b1 = tp.p[1], *W2 = tp.p[2], *b2 = tp.p[3], *W3 = tp.p[4], *b3 = tp.p[5];
+    float bw[32];
+    f32x4 bv4[8];
+    f32x4 acc[RT];
+    const f32x4 bias1 = ld4(b1 + c4), bias2 = ld4(b2 + c4), bias3 = ld4(b3 + c4);   // (ahead of the weight fragments in the load queue)
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto acc_to_Zs = [&]() {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Zs[(16 * rt + 4 * q + i) * SA + col] = acc[rt][i];
+        }
+    };
+    TS_DECL
+    board_graph<N>(gr, states72 + record_of(order, first, b) * STATE72, t);
+    load_bfrag4(bv4, W2, col, q);
+    // Every weight this kernel will read was rewritten by the previous step's Adam update and is cold in this XCD's L2.  One
+    // load per 64-byte line pulls W3 and the heads' matrices in now, under the graph setup and layer 1, instead of in front
+    // of the phases that need them (the values are summed into `warm_sink`, which is never equal to its magic number).
+    float warm[6];
+    {
+        const int l16 = t * 16;
+        warm[0] = W3[l16]; warm[1] = W3[l16 + 512 * 16];
+        warm[2] = hpm.p[0][l16]; warm[3] = hpm.p[4][l16];
+        warm[4] = l16 < A * HH ? hpm.p[2][l16] : 0.f; warm[5] = l16 + 512 * 16 < A * HH ? hpm.p[2][l16 + 512 * 16] : 0.f;
+    }
+    for (int i = t; i < 15 * 32; i += 512) st4(Hs + (81 + (i >> 5)) * SA + (i & 31) * 4, f32x4{0.f, 0.f, 0.f, 0.f});   // rows 81..95: zero for good
+    __syncthreads();
+    TS(8, 0)
+    // ---- forward, layer 1 (K = 6 padded to 8)
+    {
+        const float w_lo = W1[col * TF + q];
+        const float w_hi = (q < 2) ? W1[col * TF + 4 + q] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = mfma4(gr.x0[(16 * rt + r16) * 8 + q], w_lo, a);
+            a = mfma4(gr.x0[(16 * rt + r16) * 8 + 4 + q], w_hi, a);
+            acc[rt] = a;
+        }
+        acc_to_Zs();
+    }
+    __syncthreads();
+    auto aggregate_relu = [&](const f32x4 bv, float* __restrict__ hglob) {          // Zs -> Hs (+ memory)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int n = rg + 16 * it;
+            if (n < V) {
+                const f32x4 a = relu4(agg_row<SA>(Zs, gr, n, c4) + bv);
+                st4(Hs + n * SA + c4, a);
+                if (hglob) st4(hglob + ((size_t)b * V + n) * TH + c4, a);
+            }
+        }
+    };
+    aggregate_relu(bias1, h1);
+    const float warm_sink = ((warm[0] + warm[1]) + (warm[2] + warm[3])) + (warm[4] + warm[5]);
+    __syncthreads();
+    TS(8, 1)
+    // ---- layer 2
+    zero_acc();
+    mfma_rows_reg4<RT>(acc, Hs, bv4, r16, q);
+    TS(8, 2)
+    load_bfrag4(bv4, W3, col, q);
+    acc_to_Zs();
+    __syncthreads();
+    aggregate_relu(bias2, h2);
+    __syncthreads();
+    TS(8, 3)
+    // ---- layer 3 + mean pool (H3 stays in LDS: the backward needs only its sign)
+    zero_acc();
+    mfma_rows_reg4<RT>(acc, Hs, bv4, r16, q);
+    TS(8, 4)
+    acc_to_Zs();
+    __syncthreads();
+    {
+        const f32x4 bv = bias3;
+        f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int n = rg + 16 * it;
+            if (n < V) {
+                const f32x4 a = relu4(agg_row<SA>(Zs, gr, n, c4) + bv);
+                st4(Hs + n * SA + c4, a);
+                colsum += a;
+            }
+        }
+        st4(Hb + rg * TH + c4, colsum);                              // (Hb is free until the backward loads H2 into it)
+    }
+    __syncthreads();
+    if (t < TH) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += Hb[r * TH + t];
+        s /= (float)V;                                               // global_mean_pool
+        hsm.gs[t] = s;
+        g_out[(size_t)b * TH + t] = s;                               // (the head weight gradients are batch dot products with it)
+    }
+    TS(8, 5)
+    // ---- heads, losses, head gradients (its first barrier publishes gs)
+    heads_board<8>(hsm, b, nullptr, hpm, pi_all, z_all, order, first, A, B, hp, hv, lg, pol, vp, val, loss, dhp, dhv, nullptr);
+    TS(8, 6)
+    load_bfrag(bw, W3, TH, 1, col, q);                               // the data gradient's fragments of W3 (B[j][k] = W3[j][k]): land under layer 3's backward
+    // ---- backward.  One layer: dP (accumulator layout) -> Zs;  dZ = A_hat dP -> Hs;  dW partial = dZ^T H_{l-1} (Hb)
+    RowTile<V, VK, 512> hin;
+    auto mask_and_bias_grad = [&](const float* M, int stride) -> float {   // acc (.)= [M > 0]; returns this lane's column sum
+        float dbp = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = 16 * rt + 4 * q + i;
+                if (!(n < V && M[n * stride + col] > 0.f)) acc[rt][i] = 0.f;
+                dbp += acc[rt][i];
+            }
+        }
+        return dbp;
+    };
+    auto finish_layer = [&](float dbp, const float* __restrict__ hprev, float* __restrict__ pdb) {
+        // callers have passed a barrier since the last read of Zs / of Hs as an A operand / of Hb as a mask
+        acc_to_Zs();
+        cs[q * TH + col] = dbp;
+        if (hprev) hin.issue(hprev + (size_t)b * V * TH, t);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int n = rg + 16 * it;
+            if (n < V) st4(Hs + n * SA + c4, agg_row<SA>(Zs, gr, n, c4));                 // dZ = A_hat dP (A_hat is symmetric)
+        }
+        if (t < TH) pdb[(size_t)b * TH + t] = (cs[t] + cs[TH + t]) + (cs[2 * TH + t] + cs[3 * TH + t]);
+        if (hprev) hin.template land<SB>(Hb, t);
+        __syncthreads();
+    };
+    auto weight_grad = [&](float* __restrict__ pdW) {                  // rows 16 wave .. of W_l, all 128 columns
+        f32x4 wacc[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) wacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < VK / 4; ++ks) {
+            const float a = Hs[(4 * ks + q) * SA + 16 * wave + r16];
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) wacc[ct] = mfma4(a, Hb[(4 * ks + q) * SB + 16 * ct + r16], wacc[ct]);
+        }
+        float* dst = pdW + (size_t)b * TH * TH + (size_t)(16 * wave + 4 * q) * TH + r16;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[(size_t)i * TH + 16 * ct] = wacc[ct][i];
+        }
+    };
+    // layer 3: dH3 = dg / V on every node (global_mean_pool backward); the mask is H3, still in Hs
+    {
+        const float v = (hsm.part[col] + hsm.part[TH + col]) / (float)V;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{v, v, v, v};
+        const float dbp = mask_and_bias_grad(Hs, SA);
+        __syncthreads();                                             // everybody has read dg (in Zs) and H3 (in Hs)
+        finish_layer(dbp, h2, part_db + (size_t)2 * B * TH);
+        TS(8, 7)
+        weight_grad(part_dW3);
+        TS(8, 8)
+    }
+    // layer 2: dH2 = dZ3 W3, mask H2 (in Hb)
+    {
+        zero_acc();
+        mfma_rows_reg<RT>(acc, Hs, bw, r16, q);
+        TS(8, 9)
+        load_bfrag(bw, W2, TH, 1, col, q);
+        const float dbp = mask_and_bias_grad(Hb, SB);
+        __syncthreads();                                             // dZ3 (Hs) and H2 (Hb) are dead
+        finish_layer(dbp, h1, part_db + (size_t)B * TH);
+        TS(8, 10)
+        weight_grad(part_dW2);
+        TS(8, 11)
+    }
+    // layer 1: dH1 = dZ2 W2, mask H1 (in Hb); dW1 = dZ1^T X0 (six feature columns of one padded tile)
+    {
+        zero_acc();
+        mfma_rows_reg<RT>(acc, Hs, bw, r16, q);
+        TS(8, 12)
+        const float dbp = mask_and_bias_grad(Hb, SB);
+        __syncthreads();
+        finish_layer(dbp, nullptr, part_db);
+        TS(8, 13)
+        f32x4 wacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < VK / 4; ++ks)
+            wacc = mfma4(Hs[(4 * ks + q) * SA + 16 * wave + r16], r16 < 8 ? gr.x0[(4 * ks + q) * 8 + r16] : 0.f, wacc);
+        if (r16 < TF) {
+            float* dst = part_dW1 + (size_t)b * TH * TF + (size_t)(16 * wave + 4 * q) * TF + r16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i * TF] = wacc[i];
+        }
+        TS(8, 14)
+    }
+    if (warm_sink == -1.2345678e-31f) part_db[0] = warm_sink;          // (keeps the warm-up loads alive; never taken)
+}
+
+// ---------------------------------------------------------------------------------------------
 // gradient of every parameter element + its Adam update.   One thread per element of the 14 tensors.
 // parameter order = state_dict order (KEYS in INTEGRATION.md):
 //  0 gcn0.w [H,F]  1 gcn0.b  2 gcn1.w [H,H]  3 gcn1.b  4 gcn2.w  5 gcn2.b
@@ -708,11 +1021,26 @@ __global__ __launch_bounds__(256) void train_final_kernel(FinalJobs jb) {
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+int g_train_fused = 1;    // aqg_set_option("train_fused"): 1 = one workgroup per position for the whole forward + backward, 0 = six launches
+
 template <int N>
 static void launch_forward_backward(const aqg_train& t, const uint8_t* states72, const float* pi, const float* z, const int64_t* order,
                                     int first, int B, hipStream_t st) {
     const int A = t.policy_size;
     float* const* P = t.params;
+    if (g_train_fused) {
+        float* pdW3 = t.part;
+        float* pdW2 = pdW3 + (size_t)B * TH * TH;
+        float* pdW1 = pdW2 + (size_t)B * TH * TH;
+        float* pdb = pdW1 + (size_t)B * TH * TF;
+        TrunkParams tpm;
+        for (int i = 0; i < 6; ++i) tpm.p[i] = P[i];
+        HeadParams hpm;
+        for (int i = 0; i < 8; ++i) hpm.p[i] = P[6 + i];
+        hipLaunchKernelGGL(train_board_kernel<N>, dim3(B), dim3(512), 0, st, states72, order, first, tpm, hpm, pi, z, A, B, t.h1, t.h2, t.g,
+                           t.hp, t.hv, t.lg, t.pol, t.vp, t.val, t.loss, t.dhp, t.dhv, pdW3, pdW2, pdW1, pdb);
+        return;
+    }
     const dim3 grid(2 * B), block(256);
     float* pdW3 = t.part;
     float* pdW2 = pdW3 + (size_t)B * TH * TH;
@@ -809,8 +1137,8 @@ int train_steps(const aqg_train& t, const uint8_t* states72, const float* pi, co
 
 #ifdef AQG_STAMP
 extern "C" int aqg_debug_train_stamps(unsigned long long* out_host, int reset) {
-    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_train_stamp), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[64] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_train_stamp), z, sizeof(z)) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_train_stamp), sizeof(unsigned long long) * 160) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[160] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_train_stamp), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif

@@ -316,12 +316,14 @@ def main():
         train_leg = {"workload": "train_network.py epoch on the GNN: forward + CE(softmaxed policy) + MSE + backward + Adam, fp32, batch 128, "
                                  f"{nsteps} steps in one aqg_gcn_train_steps call (shuffle applied once per epoch)",
                      "ms_per_step": train_ms, "positions_per_s": BATCH_SIZE / (train_ms * 1e-3), "ms_per_step_single_calls": step_ms,
-                     "launches_per_step": 7,
-                     "roofline": {"kernel": "train_fwd12/fwd3/heads/bwd<3,2,1>/final (f32 MFMA 16x16x4)", "bound": "mfma", "achieved": tflops,
+                     "launches_per_step": 2,
+                     "roofline": {"kernel": "train_board_kernel<9> (one workgroup per position: forward + heads + backward, f32 MFMA 16x16x4) + train_final_kernel", "bound": "mfma", "achieved": tflops,
                                   "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": tflops * 1e12 / PEAK_F32_MFMA,
                                   "flop_per_position": TRAIN_FLOP_PER_POSITION,
-                                  "note": "2.2 GFLOP per step in 7 dependent launches that each start from a cold L2 (the previous launch ran on "
-                                          "other XCDs): the step is latency-bound, profiles/r02_train_step_*.{csv,log}"}}
+                                  "note": "2.2 GFLOP per step; one 8-wave workgroup per position keeps every activation on its CU, so batch 128 "
+                                          "occupies 128 of the 256 CUs: the f32 matrix pipe of those CUs is busy ~48 % of the kernel "
+                                          "(profiles/r02_train_step_phase_stamps.log), i.e. the reachable roof at this batch size is half the "
+                                          "quoted peak"}}
         del trainer, tr_model
 
     large = None

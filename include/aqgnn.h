@@ -36,7 +36,8 @@ const char* aqg_last_error(void);
 /* tuning knobs: "trunk_variant" 0/1 = exact f32-input MFMA with 1/2 workgroups per CU, 3 = all-MFMA fp16 split trunk
  * (hi*hi + hi*lo + lo*hi: fp32-equivalent products; default = the 8-wave x 2-per-CU form, also selected by 6), 4 / 5 = the
  * 4-wave x 2-per-CU form; "step_variant" 1/0 = one-load-round MCTS step / round-1 step, "step_fast_depth" = tree depth at which
- * the fast step hands over to memory mode; "fuse_heads" 1 = heads inside the trunk workgroup (measured slower, default 0);
+ * the fast step hands over to memory mode; "fuse_heads" 1 = heads inside the trunk workgroup (measured slower, default 0); "train_fused" 1/0 = training step as one
+ * workgroup per position / as the six-launch column-split chain (csrc/gcn_train.hip);
  * "trunk_phase_delay" = start offset of the second- / third-resident workgroups in units of 64 cycles, applied to
  * launches of at least "trunk_delay_min_boards" boards; "use_graph" 0/1 = replay
  * a move's 3*sims+2 launches as one captured hipGraph when the stream is capturable (default 1); "profile_trunk" 0/1/2 = no event pairs / around trunk launches / around MCTS step launches */
@@ -209,7 +210,7 @@ int aqg_engine_root_visits(const aqg_engine* e_host, int32_t* visits, uint8_t* a
 /* One optimisation step on a batch of positions: forward, the reference's losses (CrossEntropyLoss applied to the
  * already-softmaxed policy with probability targets train_network.py:54,85 + MSELoss on the tanh value :55,86),
  * backward, and torch.optim.Adam's update (:56,:90-92).  fp32 throughout, every contraction over the node rows on the
- * f32 matrix pipe; seven launches per step (csrc/gcn_train.hip).  mode 0 = gradients only (into grads),
+ * f32 matrix pipe; two launches per step: one workgroup per position for forward + backward, one fixed-order reduction + Adam (csrc/gcn_train.hip).  mode 0 = gradients only (into grads),
  * 1 = gradients + update, 2 = update only from whatever grads holds -- data-parallel training computes local gradients
  * (mode 0), all-reduces them over RCCL, and applies them (mode 2).  The 14 parameter tensors
  * are the state_dict tensors themselves in their PyTorch layouts and in the key order of KEYS in INTEGRATION.md; grads,

@@ -664,12 +664,16 @@ def _train_batch(B, seed, N=9):
     return recs, pi.astype(np.float32), z.astype(np.float32)
 
 
-def test_train_step_gradients_vs_autograd(dev):
+@pytest.mark.parametrize("fused", [1, 0])
+def test_train_step_gradients_vs_autograd(dev, fused):
     """aqg_gcn_train_step (fp32 HIP kernels) against torch autograd in fp64 (oracle/train.py): forward outputs, both
     losses and all 14 gradients.  Stated tolerance: gradients within 2e-5 * max|g| + 1e-7 per tensor (fp32 accumulation
-    over 10,368 nodes), losses within 1e-5 relative."""
+    over 10,368 nodes), losses within 1e-5 relative.  Both forms of the step: one workgroup per position for the whole
+    forward + backward (default), and the six-launch column-split chain."""
+    from alphaquoridorgnn_amd import _lib
     from alphaquoridorgnn_amd.train_network import GNNTrainer
     from oracle import gnn as og, train as ot
+    _lib.set_option("train_fused", fused)
     model, params = _model(2)
     recs, pi, z = _train_batch(48, 0)
     tr = GNNTrainer(model, max_batch=64)
@@ -680,6 +684,7 @@ def test_train_step_gradients_vs_autograd(dev):
     np.testing.assert_allclose(val.cpu().numpy(), ref["value"], atol=1e-5, rtol=1e-4)
     assert abs(float(pl) - ref["policy_loss"]) <= 1e-5 * abs(ref["policy_loss"])
     assert abs(float(vl) - ref["value_loss"]) <= 1e-5 * abs(ref["value_loss"]) + 1e-7
+    _lib.set_option("train_fused", 1)
     for k, gt in zip(og.KEYS, tr.grads):
         r = ref["grads"][k]
         tol = 2e-5 * np.abs(r).max() + 1e-7

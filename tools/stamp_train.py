@@ -15,13 +15,14 @@ from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
 from alphaquoridorgnn_amd.train_network import GNNTrainer, BATCH_SIZE
 from tools.microbench import synth_states
 dev = _lib.require_gpu("cuda:0"); lib = _lib.load()
+_lib.set_option("train_fused", int(os.environ.get("AQG_TRAIN_FUSED", "1")))
 model = GNNNetwork().to(dev); tr = GNNTrainer(model, max_batch=BATCH_SIZE)
 n = BATCH_SIZE * 50
 st = synth_states(n); A = model.policy_output_size
 pi = torch.rand((n, A), device=dev); pi = pi / pi.sum(1, keepdim=True)
 z = torch.randint(-1, 2, (n,), device=dev).float()
 order = torch.randperm(n, device=dev)
-buf = (ctypes.c_ulonglong * 64)()
+buf = (ctypes.c_ulonglong * 160)()
 fn = lib.aqg_debug_train_stamps; fn.restype = ctypes.c_int; fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 tr.run_epoch(st, pi, z, order[:BATCH_SIZE * 5]); torch.cuda.synchronize(); fn(buf, 1)
 tr.run_epoch(st, pi, z, order); torch.cuda.synchronize(); fn(buf, 0)
@@ -32,8 +33,16 @@ names = {0: ("fwd12", ["loads + graph", "layer-1 mfma", "aggregate 1 (128 cols)"
          4: ("bwd<2>", ["loads + graph", "dgrad mfma", "mask + barrier", "acc -> LDS + barrier", "aggregate + stores", "weight gradient"]),
          5: ("bwd<1>", ["loads + graph", "dgrad mfma", "mask + barrier", "acc -> LDS + barrier", "aggregate", "weight gradient"]),
          6: ("final", ["index", "sums", ]),}
+names[7] = ("heads inside the fused kernel", ["wait for pooled g", "hidden layers", "logits", "softmax/loss reductions", "dhp partials", "dhs", "dg partials"])
+names[8] = ("train_board (fused)", ["loads + graph", "layer 1 + aggregate", "layer-2 mfma", "acc->LDS, aggregate 2", "layer-3 mfma", "aggregate 3 + pool", "heads (all)",
+                                    "bwd3: mask, dP, aggregate", "bwd3: weight gradient", "bwd2: dgrad mfma", "bwd2: mask, dP, aggregate", "bwd2: weight gradient",
+                                    "bwd1: dgrad mfma", "bwd1: mask, dP, aggregate", "bwd1: weight gradient"])
+if os.environ.get("AQG_TRAIN_FUSED", "1") == "1":
+    names = {k: v for k, v in names.items() if k in (6, 7, 8)}
+else:
+    names = {k: v for k, v in names.items() if k < 7}
 for k, (nm, ph) in names.items():
-    row = [buf[k * 8 + i] / 50 for i in range(8)]
+    row = [buf[k * 16 + i] / 50 for i in range(16)]
     print(f"{nm}: total {sum(row):.0f} cycles per launch (workgroup 0)")
     for i, p in enumerate(ph):
         print(f"    {p:28s} {row[i]:9.0f}")
