@@ -220,7 +220,10 @@ def main():
 
     step_leg = refill_leg = train_leg = None
     if world == 1 and not args.no_extra_legs:
-        import ctypes
+        # (every MultiSetSelfPlay of a process runs on the same four streams, engine._SET_STREAMS: a second engine on four NEW streams
+        # would share hardware queues with the first one's idle streams and ran 35 % slower)
+        del eng
+        torch.cuda.empty_cache()
         # ---- the fused MCTS step kernel alone: one wavefront per game, one dependent chain of loads per tree level
         step_leg = {"kernel": "engine_step_fast_kernel<9> (backup + expansion of the previous simulation, PUCT descent, legal moves of the leaf)",
                     "bound": "latency", "us_per_launch": {}, "game_steps_per_s": {}, "waves_per_simd": {}}
@@ -328,7 +331,6 @@ def main():
 
     large = None
     if world == 1 and args.large_games > 0 and not args.no_extra_legs:
-        del eng
         torch.cuda.empty_cache()
         eng = MultiSetSelfPlay(model, num_games=args.large_games, sims=args.sims, num_sets=args.sets, seed=77)
         for _ in range(2):                    # two untimed moves: graph capture, first-touch of the 14 GB tree pools
