@@ -874,6 +874,23 @@ def test_train_cycle_on_5x5_board(dev, tmp_path):
     assert (tmp_path / "models" / "GNN" / "5x5" / "latest.pth").exists() and len(list((tmp_path / "data").glob("*.history"))) == 1
 
 
+def test_multiset_engines_share_one_set_of_streams(dev):
+    """Every MultiSetSelfPlay of a process runs on the same K streams (engine._SET_STREAMS): torch's stream pool is never
+    destroyed and the runtime maps streams onto 8 hardware queues, so a second engine on NEW streams would share queues with
+    the first one's idle streams and serialise two of its game sets (measured: 35 % slower generations from the second
+    self_play() of a train_cycle on).  Sharing the streams must not couple the engines' results."""
+    from alphaquoridorgnn_amd.engine import MultiSetSelfPlay
+    a = MultiSetSelfPlay(None, num_games=12, sims=8, num_sets=4, seed=3, evaluator="fake", fake_bias=5)
+    b = MultiSetSelfPlay(None, num_games=12, sims=8, num_sets=4, seed=3, evaluator="fake", fake_bias=5)
+    assert all(x is y for x, y in zip(a.streams, b.streams)) and len({s.cuda_stream for s in a.streams}) == 4
+    for _ in range(3):                     # interleaved moves of two live engines on the shared streams
+        a.move(); b.move()
+    ra, rb = a.play_generation(), b.play_generation()
+    assert ra["finished"] == rb["finished"] == 12
+    for x, y in zip(a.history_tensors(), b.history_tensors()):
+        assert torch.equal(x, y)
+
+
 def test_self_play_generations_differ_unless_seeded(dev, tmp_path, monkeypatch):
     """The reference samples from the unseeded global numpy RNG (self_play.py:57): two generations with unchanged weights
     never repeat.  Same here -- and a fixed seed (argument or AQG_SELFPLAY_SEED) reproduces a generation exactly."""
