@@ -22,7 +22,8 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                  the trunk launches of sampled moves -- one game set running alone, plain launches --, on the launch stream), against the matrix-pipe roof of the
                  fp32-equivalent fp16-split algorithm; the SURVEY 8(d) HBM figure (169,760 B/board against 8 TB/s) is
                  reported beside it as hbm_frac_survey_formula
-  cpu_baseline : the oracle (CPU restatement, kind "port") on a bounded sample of the same workload, rank 0, N=1.
+  cpu_baseline : the oracle (CPU restatement, kind "port") on a bounded sample of the same workload -- one sequential self-play
+                 loop per host core of the box's share (16), rates summed --, rank 0, N=1.
 """
 import argparse
 import json
@@ -56,26 +57,51 @@ TRUNK_HBM_BYTES_PER_BOARD_PMC = 852
 TRAIN_FLOP_PER_POSITION = 2 * TRUNK_FLOP_PER_BOARD + 2 * (2 * 81 * 128 * 128) + 6 * (2 * 81 * 5 * 128) + 3 * (FWD_FLOP_PER_BOARD - TRUNK_FLOP_PER_BOARD)
 
 
-def cpu_baseline(sims, mean_plies, budget_s=15.0):
-    """Oracle (oracle/mcts.py + oracle/gnn.py fp64 + C rules) timed on the host: bounded sample of one game."""
-    from oracle import gnn as og, mcts as om, quoridor as oq
-    oq.lib()
-    model = og.OracleModel(og.init_params(0))
-    rng = np.random.RandomState(0)
-    state = oq.State(N=9)
-    t0 = time.time()
-    plies = 0
-    while time.time() - t0 < budget_s and not state.is_done():
-        scores = om.pv_mcts_policy(model, state, 1.0, sims)
-        legal = state.legal_actions()
-        state = state.next(legal[om.choice_index(scores, rng.random_sample())])
-        plies += 1
-    dt = time.time() - t0
-    sims_per_s = plies * sims / dt
-    return {"value": (plies / dt) / max(mean_plies, 1.0), "unit": "games/s", "cores": 1, "kind": "port",
-            "sims_per_s": sims_per_s,
-            "sample": f"first {plies} plies of one {sims}-sims/move game (numpy-fp64 GNN oracle + C rules oracle, 1 thread, "
-                      f"{dt:.1f} s); games/s = plies/s / {mean_plies:.1f} mean plies per game of the GPU run"}
+_CPU_WORKER = r"""
+import sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from oracle import gnn as og, mcts as om, quoridor as oq
+sims, budget, seed = int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4])
+oq.lib()
+model = og.OracleModel(og.init_params(0))
+rng = np.random.RandomState(seed)
+state = oq.State(N=9)
+t0 = time.time()
+plies = 0
+while time.time() - t0 < budget:
+    if state.is_done():
+        state = oq.State(N=9)
+    scores = om.pv_mcts_policy(model, state, 1.0, sims)
+    legal = state.legal_actions()
+    state = state.next(legal[om.choice_index(scores, rng.random_sample())])
+    plies += 1
+print(plies, time.time() - t0)
+"""
+
+
+def cpu_baseline(sims, mean_plies, budget_s=15.0, workers=None):
+    """Oracle (oracle/mcts.py + oracle/gnn.py fp64 + C rules) timed on the host: every worker process plays the reference's
+    sequential loop (one game after the other, self_play.py:81-84) for `budget_s` seconds on one core; the workers' rates add up
+    (the reference itself is single-threaded; running one copy per core is the most it could do on this host)."""
+    import subprocess
+    if workers is None:
+        workers = max(1, min(16, os.cpu_count() or 1))        # a one-GPU box's CPU share
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, str(sims), str(budget_s), str(i)], stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, env=env, text=True) for i in range(workers)]
+    plies_per_s = 0.0
+    total_plies = 0
+    for p in procs:
+        out, _ = p.communicate(timeout=budget_s * 4 + 120)
+        pl, dt = out.split()[-2:]
+        plies_per_s += int(pl) / float(dt)
+        total_plies += int(pl)
+    return {"value": plies_per_s / max(mean_plies, 1.0), "unit": "games/s", "cores": workers, "kind": "port",
+            "sims_per_s": plies_per_s * sims,
+            "sample": f"{workers} processes x {budget_s:.0f} s of sequential {sims}-sims/move self-play each ({total_plies} plies in total; numpy-fp64 "
+                      f"GNN oracle + C rules oracle, one thread per process); games/s = summed plies/s / {mean_plies:.1f} mean plies per game "
+                      "of the GPU run"}
 
 
 def main():
