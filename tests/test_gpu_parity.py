@@ -1129,3 +1129,24 @@ def test_dropin_surface_play_and_policy(dev, tmp_path, monkeypatch):
     p, v = net.predict(State(), "cuda")
     assert p.shape == (131,) and abs(float(p.sum()) - 1) < 1e-5 and -1 <= v <= 1
     assert net.name == "GNN" and net.preprocess_input([State().to_array()]).shape == (1, 72)
+
+
+def test_bench_two_ranks_on_one_gpu(dev, tmp_path):
+    """The N > 1 path of bench.py (what the driver launches with torchrun, backend nccl = RCCL) rehearsed with two ranks sharing
+    this GPU over gloo: every rank plays its own games, the (s, pi, z) rows are all-gathered, rank 0 prints ONE JSON line whose
+    value counts the games of both ranks."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29500 + (os.getpid() % 400)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--games", "64", "--sims", "16", "--sets", "2", "--backend", "gloo", "--no-extra-legs", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "games/s" and d["steps"] == 1
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 128) < 1e-6          # 2 ranks x 64 games, all finished
+    assert d["positions_gathered_per_step"] > 128 and d["roofline"]["launches"] > 0
