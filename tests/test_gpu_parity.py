@@ -691,6 +691,33 @@ def test_train_step_gradients_vs_autograd(dev, fused):
         assert np.abs(gt.cpu().numpy().astype(np.float64) - r).max() <= tol, k
 
 
+@pytest.mark.parametrize("N", [3, 5])
+def test_train_step_gradients_small_boards(dev, N):
+    """The same gradient parity on the reference's smaller boards (constants.py:5-20): 9 / 25 nodes = 1 / 2 row tiles of the
+    per-board kernels, their own policy sizes; both forms of the step."""
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.pv_network_gnn import GraphPolicyValueNetwork
+    from alphaquoridorgnn_amd.train_network import GNNTrainer
+    from oracle import gnn as og, train as ot
+    A = N * N + 2 * (N - 1) ** 2
+    params = og.init_params(4, N=N)
+    model = GraphPolicyValueNetwork(policy_output_size=A, board_size=N)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    model = model.to(dev)
+    recs, pi, z = _train_batch(40, 2, N=N)
+    ref = ot.train_steps(params, [(recs, pi.astype(np.float64), z.astype(np.float64))])[0]
+    for fused in (1, 0):
+        _lib.set_option("train_fused", fused)
+        tr = GNNTrainer(model, max_batch=64)
+        pl, vl = tr.step(torch.from_numpy(recs), torch.from_numpy(pi), torch.from_numpy(z), update=False)
+        _lib.set_option("train_fused", 1)
+        assert abs(float(pl) - ref["policy_loss"]) <= 1e-5 * abs(ref["policy_loss"])
+        assert abs(float(vl) - ref["value_loss"]) <= 1e-5 * abs(ref["value_loss"]) + 1e-7
+        for k, gt in zip(og.KEYS, tr.grads):
+            r = ref["grads"][k]
+            assert np.abs(gt.cpu().numpy().astype(np.float64) - r).max() <= 2e-5 * np.abs(r).max() + 1e-7, (N, fused, k)
+
+
 def test_train_adam_steps_vs_torch(dev):
     """Three Adam steps (LambdaLR factors 1.0, 0.5, 0.25 as at epochs 0 / 50 / 80) from the same start: parameters after
     each step against torch.optim.Adam driven by fp64 autograd.  Adam's update lr * m / (sqrt(v) + eps) is ~lr for EVERY
