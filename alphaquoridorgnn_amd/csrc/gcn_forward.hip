@@ -982,7 +982,16 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     __shared__ TrunkSmemM<NWV> sm;
     // The two workgroups resident on a CU run identical phase sequences; a start offset for the second-resident ones
     // (phase_delay x 64 cycles) keeps one on the matrix pipe while the other does vector work.
+    const int prio_mode = phase_delay >> 16;     // static wave priorities (aqg_set_option("trunk_prio"); chosen by launch size on the host)
+    phase_delay &= 0xFFFF;
     for (int i = 0; i < (int)(blockIdx.x >> 8) * phase_delay; ++i) __builtin_amdgcn_s_sleep(1);   // 2nd / 3rd resident: 1x / 2x
+#ifndef AQG_NO_PRIO
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const bool up = ((prio_mode & 1) && wv >= 4) || ((prio_mode & 2) && blockIdx.x >= 256) || ((prio_mode & 4) && blockIdx.x < 256);
+        if (up) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     // The thread index is NOT kept in a register across the board loop (at the 128-register cap the allocator spilled it and
     // reloaded it behind an s_waitcnt vmcnt(0) that drained the weight prefetches): the wave index is a scalar, the lane index
     // is re-derived from the execution mask (two v_mbcnt) wherever it is needed.
@@ -1544,6 +1553,8 @@ AQG_TRACE_SETTER(set_trace_gcn)
 // with benign leftovers, wrong once the LDS held NaN patterns -- tools/cold_launch_check.py poisons the LDS before
 // the first launch of a process to catch exactly this class of bug).
 int g_trunk_variant = 3;
+int g_trunk_prio = -1;            // static wave priorities (bit 0: waves 4-7, bit 1: second-resident workgroups, bit 2: first); -1 = by launch size:
+                                  // both at >= 1024 boards (+2.9 % at 4,096 boards per launch, tools/prio_scan.py), none below (no gain at 480)
 int g_trunk_phase_delay = 100;   // x 64 cycles: start offset of the second-resident workgroups, applied to launches of
                                  // >= 8192 boards (+4-11 % there; a wash at the ~2,000-board launches of the MCTS; tools/phase_scan.py)
 int g_trunk_delay_min_boards = 2048;   // launches below this many boards start all workgroups together (tools/phase_scan.py:
@@ -1632,7 +1643,7 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
         // two 4-wave workgroups per CU (a wave owns 32 feature columns): half the LDS operand traffic of the 8-wave form
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0);
+        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 3 : 0)) << 16));
     } else {
         // two 8-wave workgroups per CU (a wave owns 16 feature columns): shortest latency per board AND, with four waves per
         // SIMD to hide each other's vector work, the highest throughput at every launch size (tools/trunk_scan.py)
@@ -1644,7 +1655,7 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
                                N * N + 2 * (N - 1) * (N - 1), logits, policy, value_pre, value);
             fused = true;
         } else {
-            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0);
+            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 3 : 0)) << 16));
         }
     }
     if (g_profile_trunk == 1) (void)hipEventRecord(prof_event(), st);
