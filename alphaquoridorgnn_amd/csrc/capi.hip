@@ -14,6 +14,7 @@ extern int g_trunk_delay_min_boards;
 extern int g_use_graph;
 extern int g_fuse_heads;
 extern int g_step_variant;
+extern int g_step_waves;
 extern int g_step_fast_depth;
 int profile_collect(double* total_ms, long long* launches, long long* boards, int reset);
 int launch_poison_lds(hipStream_t st);
@@ -63,6 +64,7 @@ int aqg_set_option(const char* name, int value) {
     if (name && !strcmp(name, "trunk_grid")) { g_trunk_grid = value; return 0; }
     if (name && !strcmp(name, "trunk_phase_delay")) { if (value < 0 || value > 4096) return fail("trunk_phase_delay out of range"); g_trunk_phase_delay = value; return 0; }
     if (name && !strcmp(name, "trunk_delay_min_boards")) { g_trunk_delay_min_boards = value; return 0; }
+    if (name && !strcmp(name, "step_waves")) { g_step_waves = value; return 0; }
     if (name && !strcmp(name, "step_variant")) { g_step_variant = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "step_fast_depth")) { if (value < 0 || value > 61) return fail("step_fast_depth must be 0..61"); g_step_fast_depth = value; return 0; }
     if (name && !strcmp(name, "fuse_heads")) { g_fuse_heads = value ? 1 : 0; return 0; }

@@ -422,6 +422,7 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
 #define STEP_STAMP_DECL
 #define STEP_STAMP(i)
 #endif
+int g_step_waves = 4;              // games (wavefronts) per workgroup of the fast step kernel
 int g_step_variant = 1;
 int g_step_fast_depth = 61;
 
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(256) void engine_step_fast_kernel(aqg_engine e, int
     __shared__ float polbuf[4][256];
     AQG_TRACE_BEGIN
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // 1, 2 or 4 games per workgroup (option "step_waves")
     if (g < e.num_games) game_step_fast<N>(e, g, lane, do_expand, do_select, fast_depth, polbuf[threadIdx.x >> 6]);
     AQG_TRACE_END(1, (unsigned long long)(uintptr_t)e.pooled)
 }
@@ -753,7 +754,10 @@ template <int N>
 static void launch_step(const aqg_engine& e, int do_expand, int do_select, hipStream_t st) {
     const dim3 grid((e.num_games + 3) / 4), block(256);
     if (g_profile_trunk == 2) profile_mark(st, e.num_games);       // measurement mode 2: the event pairs bracket the step launches
-    if (g_step_variant == 1) hipLaunchKernelGGL(engine_step_fast_kernel<N>, grid, block, 0, st, e, do_expand, do_select, g_step_fast_depth);
+    if (g_step_variant == 1) {
+        const int wpb = g_step_waves == 1 || g_step_waves == 2 ? g_step_waves : 4;
+        hipLaunchKernelGGL(engine_step_fast_kernel<N>, dim3((e.num_games + wpb - 1) / wpb), dim3(64 * wpb), 0, st, e, do_expand, do_select, g_step_fast_depth);
+    }
     else hipLaunchKernelGGL(engine_step_kernel<N>, grid, block, 0, st, e, do_expand, do_select);
     if (g_profile_trunk == 2) profile_mark(st, -1);
 }
@@ -962,7 +966,7 @@ template <int N>
 static int run_sims(const aqg_engine& e, hipStream_t st) {
     if (!g_use_graph || g_profile_trunk || st == nullptr || e.sims < 4) return enqueue_sims<N>(e, st);
     // every option a captured launch bakes in is part of the key: a changed option must never replay a stale graph
-    const int opts[8] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth, g_fuse_heads | ((g_trunk_prio & 0xff) << 8)};
+    const int opts[8] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth, g_fuse_heads | ((g_trunk_prio & 0xff) << 8) | (g_step_waves << 16)};
     for (const SimGraph& g : g_sim_graphs)
         if (!memcmp(&g.e, &e, sizeof(aqg_engine)) && !memcmp(g.opts, opts, sizeof(opts))) {
             if (hipGraphLaunch(g.exec, st) != hipSuccess) return fail("hipGraphLaunch");

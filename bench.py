@@ -145,6 +145,9 @@ def main():
 
     if args.trunk_grid:
         _lib.set_option("trunk_grid", args.trunk_grid)
+    for opt in ("step_waves", "trunk_prio"):                       # developer knobs through the environment (tools/*_scan.sh)
+        if os.environ.get("AQG_" + opt.upper()):
+            _lib.set_option(opt, int(os.environ["AQG_" + opt.upper()]))
     if args.trunk_variant != 3:
         _lib.set_option("trunk_variant", args.trunk_variant)
     torch.manual_seed(0)                 # random-init weights of the reference architecture (synthetic; no checkpoints)
