@@ -1004,7 +1004,6 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     int wave = wave0;
 
     int b = blockIdx.x;
-    while (b < B && active && !active[b]) b += gridDim.x;
     // A board's record lives in two VGPRs of EVERY wave (each wave fetches it itself: 24-72 bytes), one board ahead:
     //   fmt 0 (state72): rec0 = wall byte of slot `lane`, rec1 = header dword;  fmt 1 (QState): rec0 = dword `lane` (< 5)
     uint32_t rec0 = 0, rec1 = 0;
@@ -1019,7 +1018,15 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
             r0 = __builtin_amdgcn_raw_buffer_load_b32(rst, (ln < 5 ? ln : 4) * 4, bb * 24, 0);
         }
     };
-    if (b < B) fetch_record(b, rec0, rec1);
+    // The first board's record is requested BEFORE its `active` flag is known: the two loads are in flight together instead of
+    // one behind the other (one memory latency off every launch -- the MCTS's launches are one board per workgroup, ~94 % active).
+    if (b < B) {
+        fetch_record(b, rec0, rec1);
+        if (active && !active[b]) {                   // (workgroup-uniform) inactive slot: walk on to the next active board
+            do { b += gridDim.x; } while (b < B && !active[b]);
+            if (b < B) fetch_record(b, rec0, rec1);
+        }
+    }
     // once per workgroup: the padding rows no board ever writes.  No barrier here: their first reader sits behind the
     // first board's setup barrier.
     if (wave0 == 0) { const int l0 = fresh_lane(); if (l0 < 15) { sm.sqd[81 + l0] = 0.f; sm.dnv[81 + l0] = 0.f; } }
