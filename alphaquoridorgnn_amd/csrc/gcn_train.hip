@@ -735,7 +735,8 @@ __global__ __launch_bounds__(512) void train_board_kernel(const uint8_t* __restr
         warm[2] = hpm.p[0][l16]; warm[3] = hpm.p[4][l16];
         warm[4] = l16 < A * HH ? hpm.p[2][l16] : 0.f; warm[5] = l16 + 512 * 16 < A * HH ? hpm.p[2][l16 + 512 * 16] : 0.f;
     }
-    for (int i = t; i < 15 * 32; i += 512) st4(Hs + (81 + (i >> 5)) * SA + (i & 31) * 4, f32x4{0.f, 0.f, 0.f, 0.f});   // rows 81..95: zero for good
+    for (int i = t; i < (96 - V) * 32; i += 512) st4(Hs + (V + (i >> 5)) * SA + (i & 31) * 4, f32x4{0.f, 0.f, 0.f, 0.f});   // rows V..95: zero for good
+                                                                     // (the padding rows of every contraction over the nodes)
     __syncthreads();
     TS(8, 0)
     // ---- forward, layer 1 (K = 6 padded to 8)

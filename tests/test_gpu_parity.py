@@ -677,6 +677,7 @@ def test_train_step_gradients_vs_autograd(dev, fused):
     model, params = _model(2)
     recs, pi, z = _train_batch(48, 0)
     tr = GNNTrainer(model, max_batch=64)
+    _lib.poison_lds(dev)                   # NaN-fill LDS first (read-before-write defence)
     pl, vl = tr.step(torch.from_numpy(recs), torch.from_numpy(pi), torch.from_numpy(z), update=False)
     ref = ot.train_steps(params, [(recs, pi.astype(np.float64), z.astype(np.float64))])[0]
     pol, val = tr.outputs(48)
@@ -709,6 +710,7 @@ def test_train_step_gradients_small_boards(dev, N):
     for fused in (1, 0):
         _lib.set_option("train_fused", fused)
         tr = GNNTrainer(model, max_batch=64)
+        _lib.poison_lds(dev)               # NaN-fill LDS: padding rows a kernel forgot to clear poison the weight gradients
         pl, vl = tr.step(torch.from_numpy(recs), torch.from_numpy(pi), torch.from_numpy(z), update=False)
         _lib.set_option("train_fused", 1)
         assert abs(float(pl) - ref["policy_loss"]) <= 1e-5 * abs(ref["policy_loss"])
