@@ -215,7 +215,11 @@ __device__ __forceinline__ void game_select(const aqg_engine& e, int g, int lane
             } else { rec[r].w = 0.0; rec[r].p = 0.f; rec[r].n = 0; rec[r].kids = 0; rec[r].action = 0; }
         }
         t = wave_sum_i(t);
-        const float st = (float)sqrt((double)t);              // f32(math.sqrt(t))
+        // f32(math.sqrt(t)): t < 2^24 is exact in f32 and the compiler's f32 square root is correctly rounded
+        // (-fhip-fp32-correctly-rounded-divide-sqrt, the default), and rounding sqrt to 53 bits first never changes the 24-bit
+        // result (a binary64 square root cannot land within half an ulp of a binary32 midpoint unless it IS one: 53 >= 2*24 + 2)
+        // -- so the f64 Newton chain (14 dependent double-rate instructions per level) is not needed.  The reference traces pin it.
+        const float st = sqrtf((float)t);
         float best = -INFINITY; int besti = 0x7fffffff;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -607,7 +611,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
             }
         }
         t = wave_sum_dpp(t);
-        const float st = (float)sqrt((double)t);              // f32(math.sqrt(t))
+        const float st = sqrtf((float)t);                     // == f32(math.sqrt(t)), see game_select
         float sc[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
