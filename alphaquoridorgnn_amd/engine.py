@@ -242,16 +242,17 @@ _SET_STREAMS = {}     # (device index, number of sets) -> the streams every Mult
 class MultiSetSelfPlay:
     """K independent BatchedSelfPlay sets of a rank's games, each on its own HIP stream.
 
-    One set is a strictly serial chain per simulation (step -> trunk -> heads): while its latency-bound step / heads
-    kernels run, most of the chip idles, and the trunk's last boards leave CUs empty.  Games are independent, so
-    splitting them into K sets whose move() calls are enqueued round-robin on K streams lets the GPU fill those holes
-    with another set's kernels: 988 -> 1,082 games/s at K = 2 and 1,217 at K = 4 (2048 games x 200 sims, hipGraph replay
-    on).  K = 4 needs GPU_MAX_HW_QUEUES >= 5 (set to 8 by the package unless the user chose a value): with the runtime's
-    default of 4 hardware queues two of the streams share a queue, serialise, and K = 4 drops to 780 games/s; K >= 5
-    collapsed in every configuration tried (more hardware queues, mixed stream priorities; the host is not the limit: a
-    graph-replayed move costs 0.2 ms of host time against ~10 ms of GPU time).  Set k is
-    bit-identical to a stand-alone BatchedSelfPlay(num_games_k, seed = seed * 64 + k): nothing is shared but the
-    read-only packed weights."""
+    One set is a strictly serial chain per simulation (step -> trunk -> heads): while its step / heads kernels run, most of
+    the chip idles, and the trunk's last boards leave CUs empty.  Games are independent, so splitting them into K sets whose
+    move() calls are enqueued round-robin on K streams lets the GPU fill those holes with another set's kernels (2048 games x
+    200 sims, hipGraph replay on: K = 1 / 2 / 3 / 4: ~1,000 / 1,330 / 1,360 / 1,590 games/s).  K = 4 needs
+    GPU_MAX_HW_QUEUES >= 5 (set to 8 by the package unless the user chose a value): with the runtime's default of 4 hardware
+    queues two of the streams share a queue and serialise; K >= 5 collapses (~550-600 games/s): the GPU runs four compute
+    queues concurrently.  What the overlap can and cannot do is measured in DESIGN.md section 4 K4 (a round of the four sets
+    costs about the SUM of their trunk launches: two resident trunk workgroups fill a CU's register file, so the other
+    sets' kernels run in the trunks' shadow).  Set k is bit-identical to a stand-alone
+    BatchedSelfPlay(num_games_k, seed = seed * 64 + k): nothing is shared but the read-only packed weights (and the K
+    streams, which every engine of the process reuses -- see _SET_STREAMS)."""
 
     def __init__(self, model=None, num_games=2048, sims=50, num_sets=None, seed=0, device=None, quota=None, **kw):
         self.dev = _lib.require_gpu(device)
