@@ -304,3 +304,15 @@ def test_baseline_agents_play_a_game():
         s = s.next(a)
         plies += 1
     assert 4 <= plies <= 28
+
+
+def test_bench_cpu_baseline_workers():
+    """bench.py's cpu_baseline leg: N single-threaded oracle processes playing the reference's sequential self-play loop for a
+    bounded time; the rates add up and the record says how many cores were used (no GPU involved)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r = bench.cpu_baseline(8, 100.0, budget_s=2.0, workers=2)
+    assert r["cores"] == 2 and r["kind"] == "port" and r["unit"] == "games/s"
+    assert r["value"] > 0 and abs(r["sims_per_s"] - r["value"] * 100.0 * 8) <= 1e-6 * r["sims_per_s"]
