@@ -7,6 +7,7 @@ thread_local char g_err[512] = "";
 extern int g_trunk_variant;
 extern int g_profile_trunk;
 extern int g_trunk_prio;
+extern int g_heads_prio;
 extern int g_train_fused;
 extern int g_trunk_grid;
 extern int g_trunk_phase_delay;
@@ -15,6 +16,7 @@ extern int g_use_graph;
 extern int g_fuse_heads;
 extern int g_step_variant;
 extern int g_step_waves;
+extern int g_step_prio;
 extern int g_step_fast_depth;
 int profile_collect(double* total_ms, long long* launches, long long* boards, int reset);
 int launch_poison_lds(hipStream_t st);
@@ -60,10 +62,12 @@ const char* aqg_last_error(void) { return g_err; }
 
 int aqg_set_option(const char* name, int value) {
     if (name && !strcmp(name, "trunk_variant")) { if (!(value == 0 || value == 1 || value == 3 || value == 4 || value == 5 || value == 6)) return fail("trunk_variant must be 0, 1, 3, 4, 5 or 6"); g_trunk_variant = value; return 0; }
+    if (name && !strcmp(name, "heads_prio")) { g_heads_prio = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "trunk_prio")) { g_trunk_prio = value < 0 ? -1 : (value & 7); return 0; }
     if (name && !strcmp(name, "trunk_grid")) { g_trunk_grid = value; return 0; }
     if (name && !strcmp(name, "trunk_phase_delay")) { if (value < 0 || value > 4096) return fail("trunk_phase_delay out of range"); g_trunk_phase_delay = value; return 0; }
     if (name && !strcmp(name, "trunk_delay_min_boards")) { g_trunk_delay_min_boards = value; return 0; }
+    if (name && !strcmp(name, "step_prio")) { g_step_prio = value & 3; return 0; }
     if (name && !strcmp(name, "step_waves")) { g_step_waves = value; return 0; }
     if (name && !strcmp(name, "step_variant")) { g_step_variant = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "step_fast_depth")) { if (value < 0 || value > 61) return fail("step_fast_depth must be 0..61"); g_step_fast_depth = value; return 0; }

@@ -1389,9 +1389,10 @@ struct alignas(16) HeadsSmem {
 __global__ __launch_bounds__(256, 2) void gcn_heads_mm_kernel(const float* __restrict__ pooled, int B, int A,
                                                               const float* __restrict__ pk, float* __restrict__ logits,
                                                               float* __restrict__ policy, float* __restrict__ value_pre,
-                                                              float* __restrict__ value, const uint8_t* __restrict__ active) {
+                                                              float* __restrict__ value, const uint8_t* __restrict__ active, int prio) {
     __shared__ HeadsSmem sm;
     AQG_TRACE_BEGIN
+    if (prio) __builtin_amdgcn_s_setprio(1);       // a short latency chain: let it out of the trunk workgroups' way quickly (option "heads_prio")
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * 16;
@@ -1560,6 +1561,7 @@ AQG_TRACE_SETTER(set_trace_gcn)
 // with benign leftovers, wrong once the LDS held NaN patterns -- tools/cold_launch_check.py poisons the LDS before
 // the first launch of a process to catch exactly this class of bug).
 int g_trunk_variant = 3;
+int g_heads_prio = 0;             // wave priority 1 for the heads kernel (option "heads_prio")
 int g_trunk_prio = -1;            // static wave priorities (bit 0: waves 4-7, bit 1: second-resident workgroups, bit 2: first); -1 = by launch size:
                                   // both at >= 1024 boards (+2.9 % at 4,096 boards per launch, tools/prio_scan.py), none below (no gain at 480)
 int g_trunk_phase_delay = 100;   // x 64 cycles: start offset of the second-resident workgroups, applied to launches of
@@ -1671,7 +1673,7 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     if (!logits && !policy && !value_pre && !value) return 0;   // trunk only (bench: time the dominant kernel alone)
     if (variant >= 3 && A <= 14 * 16) {
         hipLaunchKernelGGL(gcn_heads_mm_kernel, dim3((B + 15) / 16), dim3(256), 0, st, (const float*)pooled, B, A, packed,
-                           logits, policy, value_pre, value, active);
+                           logits, policy, value_pre, value, active, g_heads_prio);
         return check_launch("gcn_heads_mm_kernel");
     }
     hipLaunchKernelGGL(gcn_heads_kernel, dim3((B + HB - 1) / HB), dim3(256), 0, st, (const float*)pooled, B, A, packed,

@@ -35,7 +35,7 @@ size_t boards_any_workspace_floats(int N, int B);
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
                                   float* value, const uint8_t* active, int flags, hipStream_t st);
-extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, g_profile_trunk, g_fuse_heads, g_trunk_prio;
+extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, g_profile_trunk, g_fuse_heads, g_trunk_prio, g_heads_prio;
 void profile_mark(hipStream_t st, long long units);
 int g_use_graph = 1;       // aqg_set_option("use_graph", 0) forces plain launches
 
@@ -426,6 +426,7 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
 #define STEP_STAMP_DECL
 #define STEP_STAMP(i)
 #endif
+int g_step_prio = 1;               // wave priority of the fast step kernel (0..3)
 int g_step_waves = 4;              // games (wavefronts) per workgroup of the fast step kernel
 int g_step_variant = 1;
 int g_step_fast_depth = 61;
@@ -727,6 +728,10 @@ __global__ __launch_bounds__(256) void engine_step_fast_kernel(aqg_engine e, int
     AQG_TRACE_BEGIN
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // 1, 2 or 4 games per workgroup (option "step_waves")
+    // a game's wave is a latency-bound chain that issues little: at priority 1 it wins the arbitration against a co-resident trunk
+    // workgroup's vector work, finishes sooner and gives its CU's second trunk slot back sooner (option "step_prio")
+    { const int pr = (fast_depth >> 8) & 3; if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 3) __builtin_amdgcn_s_setprio(3); }
+    fast_depth &= 0xFF;
     if (g < e.num_games) game_step_fast<N>(e, g, lane, do_expand, do_select, fast_depth, polbuf[threadIdx.x >> 6]);
     AQG_TRACE_END(1, (unsigned long long)(uintptr_t)e.pooled)
 }
@@ -760,7 +765,7 @@ static void launch_step(const aqg_engine& e, int do_expand, int do_select, hipSt
     if (g_profile_trunk == 2) profile_mark(st, e.num_games);       // measurement mode 2: the event pairs bracket the step launches
     if (g_step_variant == 1) {
         const int wpb = g_step_waves == 1 || g_step_waves == 2 ? g_step_waves : 4;
-        hipLaunchKernelGGL(engine_step_fast_kernel<N>, dim3((e.num_games + wpb - 1) / wpb), dim3(64 * wpb), 0, st, e, do_expand, do_select, g_step_fast_depth);
+        hipLaunchKernelGGL(engine_step_fast_kernel<N>, dim3((e.num_games + wpb - 1) / wpb), dim3(64 * wpb), 0, st, e, do_expand, do_select, g_step_fast_depth | ((g_step_prio & 3) << 8));
     }
     else hipLaunchKernelGGL(engine_step_kernel<N>, grid, block, 0, st, e, do_expand, do_select);
     if (g_profile_trunk == 2) profile_mark(st, -1);
@@ -970,7 +975,7 @@ template <int N>
 static int run_sims(const aqg_engine& e, hipStream_t st) {
     if (!g_use_graph || g_profile_trunk || st == nullptr || e.sims < 4) return enqueue_sims<N>(e, st);
     // every option a captured launch bakes in is part of the key: a changed option must never replay a stale graph
-    const int opts[8] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth, g_fuse_heads | ((g_trunk_prio & 0xff) << 8) | (g_step_waves << 16)};
+    const int opts[8] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth, g_fuse_heads | ((g_trunk_prio & 0xff) << 8) | (g_step_waves << 16) | (g_step_prio << 24) | (g_heads_prio << 28)};
     for (const SimGraph& g : g_sim_graphs)
         if (!memcmp(&g.e, &e, sizeof(aqg_engine)) && !memcmp(g.opts, opts, sizeof(opts))) {
             if (hipGraphLaunch(g.exec, st) != hipSuccess) return fail("hipGraphLaunch");
