@@ -992,6 +992,12 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         if (up) __builtin_amdgcn_s_setprio(1);
     }
 #endif
+    // trunk_prio bit 3: the two workgroups of a CU take turns at priority 1, phase by phase, instead of the older one winning
+    // every arbitration (otherwise the younger one's chain is 25 % longer)
+    const int prio_sel = (prio_mode & 8) ? (int)((blockIdx.x >> 8) & 1) : -1;
+    auto phase_prio = [&](int kph) {
+        if (prio_sel >= 0) { if ((kph + prio_sel) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    };
     // The thread index is NOT kept in a register across the board loop (at the 128-register cap the allocator spilled it and
     // reloaded it behind an s_waitcnt vmcnt(0) that drained the weight prefetches): the wave index is a scalar, the lane index
     // is re-derived from the execution mask (two v_mbcnt) wherever it is needed.
@@ -1151,6 +1157,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         while (bn < B && active && !active[bn]) bn += gridDim.x;
         __syncthreads();
         AQG_STAMP_AT(0)
+        phase_prio(1);
         // byte offset of this lane's rows in a bias table, (deg - 1) * 512 + 16 q with deg = round(sqd^2) (first row for the
         // padding nodes), two node tiles per register
         int toff[3];
@@ -1180,12 +1187,14 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         __builtin_amdgcn_sched_barrier(0);
         load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights: land under the aggregation + barrier
         __builtin_amdgcn_sched_barrier(0);
+        phase_prio(2);
         aggregate_store<JT, false>(sm, zh, zl, out, wave, lane, prs, 0);     // (nobody reads the planes now: stores need no barrier)
         AQG_STAMP_AT(9)
         AQG_STAMP_AT(10)
         __syncthreads();
         AQG_STAMP_AT(1)
         // ---- layer 2
+        phase_prio(3);
         request_bias<JT>(out, rs, 1, toff, wave);
         linear_split<JT>(sm, Bf, lane, zh, zl);
         AQG_STAMP_AT(2)
@@ -1198,11 +1207,13 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         AQG_STAMP_AT(12)
         __syncthreads();                                                    // every wave is done reading the planes
         AQG_STAMP_AT(13)
+        phase_prio(4);
         aggregate_store<JT, false>(sm, zh, zl, out, wave, lane, prs, 0);
         AQG_STAMP_AT(14)
         __syncthreads();
         AQG_STAMP_AT(3)
         // ---- layer 3 + mean pool
+        phase_prio(5);
         request_bias<JT>(out, rs, 2, toff, wave);
         linear_split<JT>(sm, Bf, lane, zh, zl);
         AQG_STAMP_AT(4)
@@ -1216,6 +1227,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
             fused_heads_512(hs, rs, pk, A, tid, logits ? logits + (size_t)b * A : nullptr, policy ? policy + (size_t)b * A : nullptr,
                             value_pre ? value_pre + b : nullptr, value ? value + b : nullptr);
         } else {
+            phase_prio(6);
             aggregate_store<JT, true>(sm, zh, zl, out, wave, lane, prs, b * (HID * 4));
         }
         rec0 = nrec0; rec1 = nrec1;
@@ -1562,8 +1574,10 @@ AQG_TRACE_SETTER(set_trace_gcn)
 // the first launch of a process to catch exactly this class of bug).
 int g_trunk_variant = 3;
 int g_heads_prio = 0;             // wave priority 1 for the heads kernel (option "heads_prio")
-int g_trunk_prio = -1;            // static wave priorities (bit 0: waves 4-7, bit 1: second-resident workgroups, bit 2: first); -1 = by launch size:
-                                  // both at >= 1024 boards (+2.9 % at 4,096 boards per launch, tools/prio_scan.py), none below (no gain at 480)
+int g_trunk_prio = -1;            // wave priorities (bit 0: waves 4-7, bit 1: second-resident workgroups, bit 2: first, bit 3: the two workgroups
+                                  // of a CU alternate at priority 1 phase by phase); -1 = by launch size: alternation at >= 1024 boards
+                                  // (+2-3 %: 45.3 M boards/s at 4,096, 47.9 M at 65,536; tools/prio_scan.py), none below (no gain at 480 and
+                                  // it would outrank the other sets' step kernels: -2 % games/s)
 int g_trunk_phase_delay = 100;   // x 64 cycles: start offset of the second-resident workgroups, applied to launches of
                                  // >= 8192 boards (+4-11 % there; a wash at the ~2,000-board launches of the MCTS; tools/phase_scan.py)
 int g_trunk_delay_min_boards = 2048;   // launches below this many boards start all workgroups together (tools/phase_scan.py:
@@ -1652,7 +1666,7 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
         // two 4-wave workgroups per CU (a wave owns 32 feature columns): half the LDS operand traffic of the 8-wave form
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 3 : 0)) << 16));
+        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16));
     } else {
         // two 8-wave workgroups per CU (a wave owns 16 feature columns): shortest latency per board AND, with four waves per
         // SIMD to hide each other's vector work, the highest throughput at every launch size (tools/trunk_scan.py)
@@ -1664,7 +1678,7 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
                                N * N + 2 * (N - 1) * (N - 1), logits, policy, value_pre, value);
             fused = true;
         } else {
-            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 3 : 0)) << 16));
+            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16));
         }
     }
     if (g_profile_trunk == 1) (void)hipEventRecord(prof_event(), st);
