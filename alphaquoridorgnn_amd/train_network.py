@@ -159,10 +159,29 @@ class GNNTrainer:
 
 def train_network():
     """train_network.py:26-107 on the GNN: best.pth -> NUM_EPOCH epochs over the newest .history -> latest.pth.
-    With torch.distributed initialised the positions of every batch are dealt out over the ranks (same shuffle on all
-    ranks, one gradient all-reduce per step, see GNNTrainer.step) and rank 0 writes latest.pth."""
+
+    Under torch.distributed rank 0 trains ALONE by default and the others wait at the barrier: a step at the reference's batch
+    size (128) is a latency-bound 0.083 ms on one GPU; dealt over W ranks every rank would still run its (shorter-gridded but
+    equally long) board kernel and add two collectives per step, i.e. data parallelism makes this loop slower, not faster.
+    AQG_TRAIN_DATA_PARALLEL=1 selects the data-parallel form anyway (same shuffle on all ranks, the positions of every batch
+    dealt out over the ranks, one all-reduce of the flat gradient buffer per step, GNNTrainer.step); rank 0 writes latest.pth."""
+    import os
     import torch.distributed as dist
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    if world > 1 and os.environ.get("AQG_TRAIN_DATA_PARALLEL", "0") != "1":
+        if rank == 0:
+            _train_single_process()
+        dist.barrier()          # latest.pth is complete before any rank moves on to the evaluation stage
+        return
+    _train_loop(rank, world)
+
+
+def _train_single_process():
+    _train_loop(0, 1)
+
+
+def _train_loop(rank, world):
+    import torch.distributed as dist
     model = GNNNetwork()
     model.load_state_dict(torch.load(PV_NETWORK_PATH + 'best.pth', map_location='cuda', weights_only=True))
     model = model.to('cuda')

@@ -964,10 +964,10 @@ dist.destroy_process_group()
 """
 
 
-def _run_two_ranks(tmp_path, mode):
+def _run_two_ranks(tmp_path, mode, **extra_env):
     import subprocess
     (tmp_path / "worker.py").write_text(_SHARD_WORKER)
-    env = dict(os.environ, AQG_REPO=REPO, AQG_PORT=str(29900 + os.getpid() % 90), AQG_CWD=str(tmp_path), AQG_MODE=mode)
+    env = dict(os.environ, AQG_REPO=REPO, AQG_PORT=str(29900 + os.getpid() % 90), AQG_CWD=str(tmp_path), AQG_MODE=mode, **extra_env)
     procs = [subprocess.Popen([sys.executable, str(tmp_path / "worker.py")], env=dict(env, RANK=str(r))) for r in range(2)]
     assert all(p.wait(timeout=900) == 0 for p in procs)
 
@@ -993,12 +993,14 @@ def test_sharded_self_play_two_ranks_equals_standalone_engines(dev, tmp_path):
     assert len(rows) == len(want) and rows == want
 
 
-def test_train_cycle_two_ranks(dev, tmp_path):
-    """Two whole cycles under torch.distributed (2 ranks, gloo): sharded self-play, data-parallel training on the file
-    rank 0 wrote (nobody reads it early), evaluation by rank 0 with the decision broadcast.  Both ranks must agree on the
-    promotions and hold identical weights; every cycle leaves one history file."""
+@pytest.mark.parametrize("data_parallel", ["0", "1"])
+def test_train_cycle_two_ranks(dev, tmp_path, data_parallel):
+    """Two whole cycles under torch.distributed (2 ranks, gloo): sharded self-play, training on the file rank 0 wrote (nobody
+    reads it early) -- by rank 0 alone (the default: the batch-128 step is latency-bound, sharding it cannot speed it up) or
+    data-parallel (AQG_TRAIN_DATA_PARALLEL=1) --, evaluation by rank 0 with the decision broadcast.  Both ranks must agree on
+    the promotions and hold identical weights; every cycle leaves one history file."""
     import pickle
-    _run_two_ranks(tmp_path, "cycle")
+    _run_two_ranks(tmp_path, "cycle", AQG_TRAIN_DATA_PARALLEL=data_parallel)
     outs = []
     for r in range(2):
         with open(tmp_path / f"cycle.{r}.pkl", "rb") as f:
