@@ -11,6 +11,8 @@ all-gather of the (s, pi, z) tuples over RCCL/xGMI (configs[3]).  Weak scaling: 
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   gnn_forward  : configs[1] -- pv_network_gnn forward at B=4096 synthetic boards, boards/s (HIP events)
+  legal_mask   : SURVEY 8(d)'s second kernel -- batched State.legal_actions() at 4,096 and 65,536 states: states/s from per-launch
+                 HIP event pairs (median / min / max), hbm_frac = states/s x 100 B / 8 TB/s (<< 1, stated), the CPU oracle beside it
   step_kernel  : the fused MCTS step (engine_step_fast_kernel): latency-bound, so its entry is us per launch at 512 and
                  4,096 games (HIP events over 160 back-to-back launches on mid-game trees), wavefronts per SIMD and
                  game-steps/s instead of a bandwidth fraction
@@ -48,10 +50,13 @@ PEAK_F16_MFMA = 2500.0e12                                            # MI355X_MI
 SPLIT_TERMS = 3                                                      # hi*hi + hi*lo + lo*hi per f32 product
 TRUNK_MFMA_PER_BOARD = 4 * (12 + 2 * 144 + 3 * 40)                   # 16x16x32 fp16 MFMAs issued per board (incl. aggregation, padding)
 PEAK_HBM = 8.0e12
-# HBM bytes per board actually moved by the default trunk, from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-# WRITE_SIZE, separate passes; profiles/r01_trunk_mm_hbm_pmc.csv, B = 65,536 boards per launch).  PMC counters
-# cannot be collected from inside this process, so `roofline.traffic` = this per-board figure x boards per launch.
-TRUNK_HBM_BYTES_PER_BOARD_PMC = 852
+# Compulsory global traffic of the default trunk per board: the 72-byte record (24 inside the engine) in, the 512-byte pooled
+# row out; the weight fragments are served by the L2 (hit rate 97.6-99.5 %, profiles/r02_pmc_l2_summary.csv).  PMC counters
+# cannot be collected from inside this process; what a rocprofv3 pass of THIS round measured is in profiles/r03_pmc_summary.csv
+# and quoted in DESIGN.md section 5 -- `roofline.traffic` stays null in the line rather than carrying a constant.
+TRUNK_COMPULSORY_BYTES_PER_BOARD = 72 + 512
+LEGAL_BYTES_PER_STATE = 100                                          # 68 B in + 27 B (209 bits) out ~ 100 B/state
+REF_LEGAL_MS_PER_STATE_PY = 4.95                                     # the reference's State.legal_actions(), 1 core (python)
 # training step, per position: forward trunk + the three weight gradients (same contractions) + the two data gradients
 # (layers 3, 2) + six aggregations (5 terms x 81 nodes x 128 columns) + the heads forward and twice backward
 TRAIN_FLOP_PER_POSITION = 2 * TRUNK_FLOP_PER_BOARD + 2 * (2 * 81 * 128 * 128) + 6 * (2 * 81 * 5 * 128) + 3 * (FWD_FLOP_PER_BOARD - TRUNK_FLOP_PER_BOARD)
@@ -80,6 +85,33 @@ print(plies, time.time() - t0)
 """
 
 
+_CPU_LEGAL_WORKER = r"""
+import sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from oracle import quoridor as oq
+oq.lib()
+recs = np.load(sys.argv[2])
+oq.legal_actions_batch(recs[:64])
+t = time.time()
+oq.legal_actions_batch(recs)
+print(len(recs) / (time.time() - t))
+"""
+
+
+def cpu_legal_baseline(sample):
+    """oracle/quoridor_oracle.c (the reference's array/queue legal_actions in C) on `sample` states, one core: states/s."""
+    import subprocess
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"aqg_legal_sample_{os.getpid()}.npy")
+    np.save(path, sample)
+    try:
+        out = subprocess.run([sys.executable, "-c", _CPU_LEGAL_WORKER, ROOT, path], capture_output=True, text=True, timeout=300)
+        return float(out.stdout.split()[-1])
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+
+
 def cpu_baseline(sims, mean_plies, budget_s=15.0, workers=None):
     """Oracle (oracle/mcts.py + oracle/gnn.py fp64 + C rules) timed on the host: every worker process plays the reference's
     sequential loop (one game after the other, self_play.py:81-84) for `budget_s` seconds on one core; the workers' rates add up
@@ -102,6 +134,47 @@ def cpu_baseline(sims, mean_plies, budget_s=15.0, workers=None):
             "sample": f"{workers} processes x {budget_s:.0f} s of sequential {sims}-sims/move self-play each ({total_plies} plies in total; numpy-fp64 "
                       f"GNN oracle + C rules oracle, one thread per process); games/s = summed plies/s / {mean_plies:.1f} mean plies per game "
                       "of the GPU run"}
+
+
+def legal_mask_leg(dev, lib, _lib, synth_states):
+    """SURVEY 8(d) second kernel: batched State.legal_actions() (game_logic.py:103-117, BFS :309-348) -- legal_actions_kernel<9>,
+    one wavefront per state, mask + ordered list + count written.  Every launch sits between its own HIP event pair on the
+    launch stream, so a host hiccup between launches shows up as ONE long sample (max_us) instead of inflating the mean
+    (round 2's unexplained '481 us at B = 512' was the mean of 200 back-to-back launches behind one event pair)."""
+    leg = {"kernel": "legal_actions_kernel<9> (one wavefront per state: placement masks + touch-count prefilter on the scalar unit, two jump-aware "
+                     "flood fills per candidate wall, list order by ballots)", "bound": "integer ALU / latency (not HBM)", "batches": {}}
+    for B in (4096, 65536):
+        st = synth_states(B, seed=1, dev=dev)
+        mask = torch.empty((B, 209), dtype=torch.uint8, device=dev)
+        order = torch.empty((B, 136), dtype=torch.uint8, device=dev)
+        count = torch.empty((B,), dtype=torch.int32, device=dev)
+
+        def legal():
+            _lib.check(lib.aqg_legal_actions(9, _lib.ptr(st), B, _lib.ptr(mask), _lib.ptr(order), _lib.ptr(count), _lib.stream_ptr(dev)), "legal")
+        for _ in range(10):
+            legal()
+        torch.cuda.synchronize()
+        n = 100
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        for i in range(n):
+            legal()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        us = np.asarray([ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(n)])
+        med = float(np.median(us))
+        leg["batches"][str(B)] = {"us_per_launch_median": med, "us_min": float(us.min()), "us_max": float(us.max()),
+                                  "states_per_s": B / (med * 1e-6), "hbm_frac": B / (med * 1e-6) * LEGAL_BYTES_PER_STATE / PEAK_HBM,
+                                  "mean_legal_actions": float(count.float().mean()),
+                                  "mean_walls_on_board": float((st[:, 4:68] != 0).sum(1).float().mean())}
+    leg["_sample"] = synth_states(4096, seed=1, dev=dev).cpu().numpy()     # handed to the cpu_baseline leg, removed before printing
+    leg["reference_python_states_per_s_per_core"] = 1e3 / REF_LEGAL_MS_PER_STATE_PY
+    leg["note"] = ("states/s = batch / median launch-to-launch time (HIP event pairs around every launch; max_us is the single worst pair). "
+                   "hbm_frac = states/s x 100 B / 8 TB/s, << 1 by construction: the kernel is integer-ALU and latency bound (up to 128 candidate "
+                   "walls x 2 flood fills), SURVEY 8(d); instruction mix and VALU utilisation from rocprofv3 PMC: profiles/r03_pmc_summary.csv "
+                   "(legal_* rows). The CPU oracle's states/s on 4,096 of the same states is in cpu_baseline.legal_mask_states_per_s_per_core; "
+                   "reference_python = SURVEY 8(d)'s 4.95 ms/state of the real reference measured in the build container")
+    return leg
 
 
 def main():
@@ -247,8 +320,9 @@ def main():
     _lib.set_option("trunk_variant", 3)
     fwd_ms = min(time_ms(fwd, 200, warmup=20) for _ in range(2))      # default variant, after the clocks have settled on this workload
 
-    step_leg = refill_leg = train_leg = None
+    step_leg = refill_leg = train_leg = legal_leg = None
     if world == 1 and not args.no_extra_legs:
+        legal_leg = legal_mask_leg(dev, lib, _lib, synth_states)
         # (every MultiSetSelfPlay of a process runs on the same four streams, engine._SET_STREAMS: a second engine on four NEW streams
         # would share hardware queues with the first one's idle streams and ran 35 % slower)
         del eng
@@ -399,15 +473,19 @@ def main():
             "positions_gathered_per_step": positions,
             "gnn_forward": {"workload": f"BASELINE configs[1]: pv_network_gnn forward, batch={B} synthetic boards (trunk + heads)",
                             "boards_per_s": B / (fwd_ms * 1e-3), "ms": fwd_ms, "trunk_variants": variants,
-                            "mfma_frac": B / (fwd_ms * 1e-3) * FWD_FLOP_PER_BOARD / PEAK_F32_MFMA,
+                            "mfma_frac": B / (fwd_ms * 1e-3) * FWD_FLOP_PER_BOARD / (PEAK_F16_MFMA / SPLIT_TERMS),
+                            "frac_vs_f32_input_mfma_peak": B / (fwd_ms * 1e-3) * FWD_FLOP_PER_BOARD / PEAK_F32_MFMA,
                             "hbm_frac_survey_formula": B / (fwd_ms * 1e-3) * HBM_BYTES_PER_BOARD / PEAK_HBM},
             "roofline": {"kernel": "gcn_trunk_boards_mm_kernel<1,2> (GCN trunk: linear maps + aggregation on fp16 split MFMA)", "bound": "mfma",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / SPLIT_TERMS / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / (PEAK_F16_MFMA / SPLIT_TERMS),
-                         "traffic": TRUNK_HBM_BYTES_PER_BOARD_PMC * trunk_boards / max(trunk_launches, 1),
-                         "traffic_note": "HBM bytes per launch = 852 B/board (rocprofv3 PMC on this kernel, profiles/r01_trunk_mm_hbm_pmc.csv: 584 B/board "
-                                         "compulsory record-in + pooled-out, the rest is the L2-missing share of the weight fragments) x boards per launch; "
-                                         "the algorithmic layer-granular figure is 169,760 B/board (hbm_frac_survey_formula): activations never leave LDS",
+                         "traffic": None,
+                         "traffic_note": "HBM is not a roof of this kernel: activations never leave LDS, the weight fragments come from L2; compulsory "
+                                         f"traffic is {TRUNK_COMPULSORY_BYTES_PER_BOARD} B/board (record in + pooled row out) = "
+                                         f"{boards_per_s_kernel * TRUNK_COMPULSORY_BYTES_PER_BOARD / PEAK_HBM * 100:.2f} % of 8 TB/s at this rate; "
+                                         "PMC-measured bytes of this round: profiles/r03_pmc_summary.csv (collected by a separate rocprofv3 pass, "
+                                         "quoted in DESIGN.md section 5); the algorithmic layer-granular figure is 169,760 B/board (hbm_frac_survey_formula)",
+                         "frac_vs_dense_f16_peak": achieved / PEAK_F16_MFMA,
                          "launches": trunk_launches, "avg_launch_us": trunk_ms / max(trunk_launches, 1) * 1e3,
                          "boards_per_launch_avg": trunk_boards / max(trunk_launches, 1),
                          "launches_sampled": "every trunk launch of one game set's move on plies 13/41/69/97 of each timed generation; that set runs alone on the GPU with plain launches for that move, all other moves replay captured hipGraphs with the sets overlapping",
@@ -420,10 +498,15 @@ def main():
                                  "the exact f32-input MFMA variant). "
                                  "achieved = ALGORITHMIC f32 FLOP/s (5,432,832 per board x boards / kernel time from HIP events around "
                                  "every launch); peak = dense fp16 MFMA peak / 3 split terms = the matrix-pipe roof of this algorithm "
-                                 "(the exact f32-input MFMA roof of SURVEY 8d is 157.3 TFLOP/s: frac_vs_f32_input_mfma_peak). Launches "
-                                 "inside the MCTS are ~2,000 boards = 4 per CU, so avg_launch_us carries the wave-quantisation tail; "
-                                 "gnn_forward.trunk_variants is the same kernel at 4,096 boards per launch"},
+                                 "(the exact f32-input MFMA roof of SURVEY 8d is 157.3 TFLOP/s: frac_vs_f32_input_mfma_peak; against the plain dense "
+                                 "fp16 peak of 2.5 PFLOP/s: frac_vs_dense_f16_peak). Launches inside the MCTS carry one game set's leaves, ~480 "
+                                 "boards = one board per workgroup (512 workgroups, two per CU), so avg_launch_us is one board's latency chain "
+                                 "plus the launch overhead; gnn_forward.trunk_variants is the same kernel at 4,096 boards per launch. Matrix-pipe "
+                                 "busy share (SQ_VALU_MFMA_BUSY_CYCLES) from the PMC passes of this round: profiles/r03_pmc_summary.csv"},
         }
+        legal_sample = legal_leg.pop("_sample", None) if legal_leg is not None else None
+        if legal_leg is not None:
+            out["legal_mask"] = legal_leg
         if step_leg is not None:
             out["step_kernel"] = step_leg
         if refill_leg is not None:
@@ -435,6 +518,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.sims, mean_plies)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+            if legal_sample is not None:
+                out["cpu_baseline"]["legal_mask_states_per_s_per_core"] = cpu_legal_baseline(legal_sample)
+                out["cpu_baseline"]["legal_mask_sample"] = "oracle C rules (the reference's algorithm) on 4,096 of the legal_mask leg's states, one core"
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

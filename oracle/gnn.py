@@ -130,6 +130,63 @@ def forward_states(params, recs):
     return forward_graph(params, np.concatenate(xs), np.concatenate(es, axis=1), np.concatenate(bs), len(recs))
 
 
+def forward_states_dense(params, recs, chunk=1024):
+    """The same forward as forward_states(), vectorised over boards with dense [V, V] adjacencies (one fp64 batched matmul per
+    layer instead of a Python loop per tile): what the GPU parity tests use at the full BASELINE sizes (4,096 boards in
+    seconds).  Same definitions, re-derived independently of the edge-list code above: tests/test_oracle_golden.py checks
+    that the two agree to 1e-12 on reference-walk states, so the slow form stays the statement and this one the tool."""
+    recs = np.asarray(recs, dtype=np.uint8).reshape(-1, 72)
+    p = {k: np.asarray(v, dtype=np.float64) for k, v in params.items()}
+    outs = []
+    for c0 in range(0, recs.shape[0], chunk):
+        r = recs[c0:c0 + chunk]
+        B = r.shape[0]
+        N = int(r[0, 70])
+        assert (r[:, 70] == N).all()
+        V, S = N * N, N - 1
+        W = r[:, 4:4 + S * S].reshape(B, S, S)
+        Hh = np.zeros((B, S, N + 1), dtype=bool)          # horizontal wall at slot (x, y), columns padded on both sides
+        Hh[:, :, 1:N] = W == 1
+        Vv = np.zeros((B, N + 1, S), dtype=bool)          # vertical wall at slot (x, y), rows padded on both sides
+        Vv[:, 1:N, :] = W == 2
+        # game_logic.py:145-167: the step (x, y) -> (x + 1, y) is blocked by a horizontal wall at slot (x, y) or (x, y - 1);
+        # the step (x, y) -> (x, y + 1) by a vertical wall at slot (x, y) or (x - 1, y)
+        down = ~(Hh[:, :, 1:] | Hh[:, :, :N])             # [B, S, N] open between rows x and x + 1 at column y
+        right = ~(Vv[:, 1:, :] | Vv[:, :N, :])            # [B, N, S] open between columns y and y + 1 at row x
+        A = np.zeros((B, V, V), dtype=np.float64)
+        bi = np.arange(B)[:, None, None]
+        t = (np.arange(S)[:, None] * N + np.arange(N)[None, :])[None]           # tile (x, y), x < S
+        A[bi, t, t + N] = down
+        A[bi, t + N, t] = down
+        t = (np.arange(N)[:, None] * N + np.arange(S)[None, :])[None]           # tile (x, y), y < S
+        A[bi, t, t + 1] = right
+        A[bi, t + 1, t] = right
+        A[:, np.arange(V), np.arange(V)] = 1.0            # gcn_norm: one self loop of weight 1 per node
+        dis = A.sum(2) ** -0.5                            # deg[i] = weights of edges INTO i (symmetric here), >= 1
+        An = dis[:, :, None] * A * dis[:, None, :]
+        x = np.zeros((B, V, 6), dtype=np.float64)         # pv_network_cnn.py:88-114
+        rows = np.arange(B)
+        x[rows, r[:, 0].astype(int), 0] = 1.0
+        x[:, :, 1] = r[:, 1].astype(np.float64)[:, None]
+        x[rows, r[:, 2].astype(int), 2] = 1.0
+        x[:, :, 3] = r[:, 3].astype(np.float64)[:, None]
+        tw = (N * (np.arange(S * S) // S) + np.arange(S * S) % S)               # :107
+        x[:, tw, 4] = (r[:, 4:4 + S * S] == 1)
+        x[:, tw, 5] = (r[:, 4:4 + S * S] == 2)
+        h = x
+        for l in range(3):
+            h = np.maximum(An @ (h @ p[f"gcn_layers.{l}.lin.weight"].T) + p[f"gcn_layers.{l}.bias"], 0.0)
+        outs.append(h.mean(1))
+    g = np.concatenate(outs, 0) if outs else np.zeros((0, 128))
+    hp = np.maximum(g @ p["policy_head.0.weight"].T + p["policy_head.0.bias"], 0.0)
+    logits = hp @ p["policy_head.2.weight"].T + p["policy_head.2.bias"]
+    hv = np.maximum(g @ p["value_head.0.weight"].T + p["value_head.0.bias"], 0.0)
+    vpre = hv @ p["value_head.2.weight"].T + p["value_head.2.bias"]
+    e = np.exp(logits - logits.max(axis=1, keepdims=True))
+    return dict(pooled=g, logits=logits, value_pre=vpre[:, 0], policy=e / e.sum(axis=1, keepdims=True),
+                value=np.tanh(vpre[:, 0]))
+
+
 def init_params(seed=0, N=9, num_features=6, hidden=128, layers=3):
     """Random-init weights of the reference architecture: GCN `lin` Glorot-uniform, GCN bias zero (PyG),
     heads default nn.Linear init (kaiming-uniform a=sqrt(5) => U(-1/sqrt(fan_in), 1/sqrt(fan_in)))."""

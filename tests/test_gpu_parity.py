@@ -216,6 +216,100 @@ def test_gnn_forward_scaled_weights(dev, variant):
     _lib.set_option("trunk_variant", 3)
 
 
+_WALK_ORACLE = {}
+
+
+def _walk_oracle(seed):
+    """fp64 oracle outputs for ALL 14,000 reference-walk states (dense form, ~12 s once per weight seed), sliced by the tests."""
+    from oracle import gnn as og
+    if seed not in _WALK_ORACLE:
+        params = og.init_params(seed)
+        for l in range(3):      # non-zero GCN biases: the folded bias table (TB) and its per-degree rows matter at every node
+            params[f"gcn_layers.{l}.bias"] = (np.linspace(-0.3, 0.5, 128) * (1 + l)).astype(np.float32)
+        _WALK_ORACLE[seed] = (params, og.forward_states_dense(params, U.golden("walk_9x9.npz")["states"]))
+    return _WALK_ORACLE[seed]
+
+
+@pytest.mark.parametrize("variant,B", [(6, 4096), (6, 1000), (6, 2049), (5, 4096), (5, 1000), (5, 2049), (3, 8192), (1, 2049)])
+def test_gnn_forward_many_boards_per_workgroup(dev, variant, B):
+    """BASELINE configs[1] at its own size, and ragged sizes around the launch-size switches: with more than 512 boards a
+    workgroup of the persistent trunk walks SEVERAL boards (next-record prefetch, LDS reuse between boards, the conditional end
+    barrier), launches of >= 1,024 boards alternate wave priorities, launches of >= 2,048 start the second-resident workgroups
+    with an offset.  Every row against the fp64 oracle at the same tolerance as the one-board-per-workgroup test, LDS poisoned
+    first; a failing row's index mod 512 tells which loop iteration produced it."""
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+    params, ref = _walk_oracle(11)
+    model = GNNNetwork()
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    model = model.to(dev).eval()
+    _lib.set_option("trunk_variant", variant)
+    try:
+        assert model.gnn_flags(dev) == 0
+        g = U.golden("walk_9x9.npz")
+        idx = np.random.RandomState(B + variant).randint(0, g["states"].shape[0], size=B)
+        recs = torch.from_numpy(g["states"][idx]).to(dev)
+        _lib.poison_lds(dev)
+        policy, value, logits, vpre = model.forward_states(recs, want_logits=True)
+        lg, vp = logits.cpu().numpy().astype(np.float64), vpre.cpu().numpy().astype(np.float64)
+        bad = np.nonzero(~np.isclose(lg, ref["logits"][idx], atol=1e-5, rtol=1e-4).all(1) |
+                         ~np.isclose(vp, ref["value_pre"][idx], atol=1e-5, rtol=1e-4))[0]
+        assert bad.size == 0, f"{bad.size} rows off, first {bad[:8]} (row mod 512: {bad[:8] % 512})"
+        np.testing.assert_allclose(policy.cpu().numpy(), ref["policy"][idx], atol=1e-6, rtol=1e-4)
+        np.testing.assert_allclose(value[:, 0].cpu().numpy(), ref["value"][idx], atol=1e-5, rtol=1e-4)
+        # a row does not depend on which workgroup / loop iteration computed it: the same boards in another order
+        perm = torch.from_numpy(np.random.RandomState(1).permutation(B)).to(dev)
+        _lib.poison_lds(dev)
+        p2, v2 = model.forward_states(recs[perm].contiguous())
+        assert torch.equal(p2, policy[perm]) and torch.equal(v2, value[perm])
+    finally:
+        _lib.set_option("trunk_variant", 3)
+
+
+@pytest.mark.parametrize("variant", [6, 5, 1])
+def test_engine_masked_trunk_launch(dev, variant):
+    """The trunk as the ENGINE launches it: 24-byte packed leaf states (fmt 1) + the leaf_flag mask.  2,048 roots of which 35 %
+    are terminal (enemy on its goal row: game_logic.py:43-46, never evaluated, pv_mcts.py:35-42), one simulation: the rows of
+    evaluated roots must equal the mask-free forward of the same packed states bit for bit and the oracle within the
+    tolerance; the rows of masked-out roots must keep the sentinel the test put there (pooled, policy and value)."""
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+    params, ref = _walk_oracle(11)
+    model = GNNNetwork()
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    model = model.to(dev).eval()
+    G = 2048
+    g = U.golden("walk_9x9.npz")
+    rng = np.random.RandomState(77)
+    idx = rng.randint(0, g["states"].shape[0], size=G)
+    recs = g["states"][idx].copy()
+    dead = rng.rand(G) < 0.35
+    dead[:3] = [True, False, True]
+    recs[dead, 2] = recs[dead, 2] % 9                     # enemy pawn onto row 0 of its own frame: is_lose()
+    _lib.set_option("trunk_variant", variant)
+    try:
+        eng = BatchedSelfPlay(model, num_games=G, sims=1, record_history=False)
+        for name in ("pooled", "policy", "value"):
+            eng.t[name].fill_(-7.25)
+        _lib.poison_lds(dev)
+        eng.search(recs)
+        torch.cuda.synchronize()
+        live = torch.from_numpy(~dead).to(dev)
+        assert int(eng.t["stat_leaf_evals"].sum()) == int((~dead).sum())
+        for name in ("pooled", "policy", "value"):
+            assert bool((eng.t[name][~live] == -7.25).all()), name
+        # mask-free forward of the engine's own packed leaf states (the roots), same kernels: bit-identical rows
+        policy, value = model.forward_states(eng.t["leaf_state"][live].contiguous(), state_fmt=1)
+        assert torch.equal(eng.t["policy"][live], policy) and torch.equal(eng.t["value"][live], value[:, 0])
+        keep = ~dead
+        np.testing.assert_allclose(eng.t["policy"][live].cpu().numpy(), ref["policy"][idx][keep], atol=1e-6, rtol=1e-4)
+        np.testing.assert_allclose(eng.t["value"][live].cpu().numpy(), ref["value"][idx][keep], atol=1e-5, rtol=1e-4)
+        np.testing.assert_allclose(eng.t["pooled"][live].cpu().numpy(), ref["pooled"][idx][keep], atol=2e-6, rtol=1e-4)
+    finally:
+        _lib.set_option("trunk_variant", 3)
+
+
 def test_gnn_fp16_range_guard(dev):
     """The default kernels hold activations as fp16 hi + lo pairs: fp32-equivalent only inside fp16 range.  The reference's
     fp32 has no such cliff (pv_network_gnn.py:53-64), so every weight set is checked against the exact f32 kernels on
@@ -280,6 +374,8 @@ def test_gnn_small_boards_forward_and_selfplay(dev):
     pi /= pi.sum(1, keepdims=True)
     zt = rng.choice([-1.0, 0.0, 1.0], 24).astype(np.float32)
     tr = GNNTrainer(model, max_batch=24)
+    from alphaquoridorgnn_amd import _lib
+    _lib.poison_lds(dev)                   # the NaN-padding bug of round 2 was found in exactly this step
     tr.step(torch.from_numpy(tr_recs), torch.from_numpy(pi), torch.from_numpy(zt), update=False)
     refg = ot.train_steps(params, [(tr_recs, pi.astype(np.float64), zt.astype(np.float64))])[0]["grads"]
     for k, gt in zip(og.KEYS, tr.grads):
@@ -652,11 +748,31 @@ def test_multiset_selfplay_equals_standalone_sets(dev):
 
 
 # ------------------------------------------------------------------ training row
+def _walk_states(N, count, seed):
+    """Reference-walk fixture states; 7x7 (no reference constants, no fixture) from the oracle's rules by random wall-heavy play."""
+    if N != 7:
+        return U.golden(f"walk_{N}x{N}.npz")["states"]
+    from oracle import quoridor as oq
+    rng = np.random.RandomState(seed)
+    recs = []
+    while len(recs) < count:
+        s = oq.State(N=N)
+        for ply in range(40):
+            if s.is_done():
+                break
+            recs.append(s.rec.copy())
+            la = s.legal_actions()
+            walls = [a for a in la if a >= N * N]
+            pick = walls if (walls and rng.rand() < 0.5) else la
+            s = s.next(pick[rng.randint(len(pick))])
+    return np.stack(recs)
+
+
 def _train_batch(B, seed, N=9):
-    g = U.golden(f"walk_{N}x{N}.npz")
+    states = _walk_states(N, 4 * B, seed + 100)
     rng = np.random.RandomState(seed)
     A = N * N + 2 * (N - 1) ** 2
-    recs = g["states"][rng.choice(g["states"].shape[0], B, replace=False)]
+    recs = states[rng.choice(states.shape[0], B, replace=False)]
     pi = rng.rand(B, A) * (rng.rand(B, A) < 0.2)
     pi[:, 0] += 1e-3
     pi = pi / pi.sum(1, keepdims=True)
@@ -692,10 +808,11 @@ def test_train_step_gradients_vs_autograd(dev, fused):
         assert np.abs(gt.cpu().numpy().astype(np.float64) - r).max() <= tol, k
 
 
-@pytest.mark.parametrize("N", [3, 5])
+@pytest.mark.parametrize("N", [3, 5, 7])
 def test_train_step_gradients_small_boards(dev, N):
-    """The same gradient parity on the reference's smaller boards (constants.py:5-20): 9 / 25 nodes = 1 / 2 row tiles of the
-    per-board kernels, their own policy sizes; both forms of the step."""
+    """The same gradient parity on the reference's smaller boards (constants.py:5-20) and on 7x7: 9 / 25 / 49 nodes = 1 / 2 / 4
+    row tiles of the per-board kernels, their own policy sizes; both forms of the step, LDS poisoned first (the padding-row bug
+    of round 2 depended on the board size)."""
     from alphaquoridorgnn_amd import _lib
     from alphaquoridorgnn_amd.pv_network_gnn import GraphPolicyValueNetwork
     from alphaquoridorgnn_amd.train_network import GNNTrainer

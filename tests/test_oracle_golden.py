@@ -181,3 +181,21 @@ def test_choice_index_matches_numpy():
         r1 = np.random.RandomState(9)
         r2 = np.random.RandomState(9)
         assert r1.choice(n, p=p) == om.choice_index(p, r2.random_sample())
+
+
+@pytest.mark.parametrize("N", [9, 5, 3])
+def test_gnn_oracle_dense_form_equals_edge_list_form(N):
+    """oracle/gnn.py holds the GNN forward twice: the edge-list statement (gcn_conv over board_edges, PyG's scatter form) and a
+    dense-adjacency vectorisation the GPU tests use at BASELINE sizes.  They must agree to fp64 rounding on reference-walk
+    states (wall-heavy ones included) with non-zero biases."""
+    from oracle import gnn as og
+    g = U.golden(f"walk_{N}x{N}.npz")
+    p = og.init_params(5, N=N)
+    for l in range(3):
+        p[f"gcn_layers.{l}.bias"] = np.linspace(-0.4, 0.6, 128).astype(np.float32) * (l + 1)
+    nwalls = (g["states"][:, 4:68] != 0).sum(1)
+    pick = np.concatenate([np.argsort(-nwalls, kind="stable")[:40], np.arange(0, g["states"].shape[0], 97)[:80]])
+    recs = g["states"][pick]
+    a, b = og.forward_states(p, recs), og.forward_states_dense(p, recs, chunk=50)
+    for k in a:
+        assert np.abs(a[k] - b[k]).max() < 1e-12, k
