@@ -51,8 +51,8 @@ struct PackedLayout {
     // [plane 2][tile 8 (16 columns each)][kblock 4][lane 64][4 dwords = 8 fp16]   (see load_bfrag_mm)
     static constexpr size_t WH2 = WF3 + HID * HID;
     static constexpr size_t WH3 = WH2 + 2 * HID * HID / 2;
-    // layer-1 weight as fp16 B fragments with the split folded into the k dimension: per lane 8 halves,
-    // k-slots 0..7 = hi(W1[n][0..5]),0,0   8..15 = lo(W1[n][0..5]),0,0   16..31 = 0:  [tile 8][lane 64][4 dwords]
+    // layer-1 weight (times CQ) as fp16 A fragments, rows = output features, the split folded into the k dimension: per lane 8
+    // halves, k-slots 0..7 and 8..15 = hi(c W1[n][0..5]),0,0   16..23 = lo(c W1[n][0..5]),0,0   24..31 = 0:  [tile 8][lane 64][4 dwords]
     static constexpr size_t WH1 = WH3 + 2 * HID * HID / 2;
     // heads on the split matrix pipe (gcn_heads_mm_kernel): hidden layer of both heads as A fragments
     // [plane 2][unit tile 8][kblock 4][lane 64][4 dwords]  (lane = unit 16*ut + c, k = 32*kb + 8*q + 0..7), and
@@ -124,6 +124,9 @@ int pack_weights_host(int N, const float* const* t, float* out) {
                         }
     }
     {
+        // layer 1 runs aggregate-first (see the trunk comment): the wave's 16 output features are the ROWS of the A operand, the
+        // k index carries the six input features three times -- k-slots 8 q + j: q = 0 and 1 hold hi(c W1[n][j]) (they meet
+        // hi(G') and lo(G') in the B operand), q = 2 holds lo(c W1[n][j]) (meets hi(G') again), q = 3 is zero
         uint32_t* dst = reinterpret_cast<uint32_t*>(out + PackedLayout::WH1);
         for (int w = 0; w < 4; ++w)
             for (int j = 0; j < 2; ++j)
@@ -133,10 +136,10 @@ int pack_weights_host(int N, const float* const* t, float* out) {
                         uint16_t h[2] = {0, 0};
                         for (int e = 0; e < 2; ++e) {
                             const int k = 2 * d + e;
-                            if (q < 2 && k < F) {
-                                const float x = t[0][n * F + k];
+                            if (q < 3 && k < F) {
+                                const float x = (float)(CQ * (double)t[0][n * F + k]);
                                 const _Float16 hi = (_Float16)x;
-                                const _Float16 v = (q == 0) ? hi : (_Float16)(x - (float)hi);
+                                const _Float16 v = (q < 2) ? hi : (_Float16)(x - (float)hi);
                                 memcpy(&h[e], &v, 2);
                             }
                         }
@@ -208,6 +211,12 @@ __device__ __forceinline__ float dinv_of(int deg) {
 }
 
 __device__ __forceinline__ float dinv_of_bits(int bits) { return dinv_of(1 + __popc(bits)); }
+// the same as straight selects on deg - 1 (a switch on a per-lane value can compile to divergent branches)
+__device__ __forceinline__ float dinv_of_dm(uint32_t dm) {
+    const float a = dm == 0u ? 1.0f : 0.70710678118654752f, b = dm == 2u ? 0.57735026918962576f : 0.5f;
+    const float ab = dm < 2u ? a : b;
+    return dm < 4u ? ab : 0.44721359549995794f;
+}
 
 // Diagnostic build only (-DAQG_STAMP, never shipped): per-phase s_memtime sums of workgroup 0 / wave 0 are
 // written behind the pooled rows (pooled + B*128, as 16 x u64).  In the real kernel no stamp executes.
@@ -621,10 +630,12 @@ constexpr int af_nt(int blk) { return (AF_NT_PACK >> (3 * blk)) & 7; }
 template <int NWV>
 struct alignas(16) TrunkSmemM {
     alignas(16) unsigned char P[2][PPLANE];            // fp16 hi / lo planes of the activation image [node][feature] (scale CQ / D^-1/2)
-    alignas(16) unsigned int AF[AF_BLOCKS][64][4];     // B fragments of (A + I) diag(CQ / deg) of this board (fp16, exact)
-    alignas(16) unsigned int X0[81][4];                // node features as 8 fp16 (6 used)
-    alignas(16) float sqd[96];                         // deg^1/2 per node; entries 81..95 stay zero
-    alignas(16) float dnv[96];                         // deg^-1/2 per node; entries 81..95 stay zero
+    alignas(16) unsigned int AF[2][AF_BLOCKS][64][4];  // B fragments of (A + I) diag(CQ / deg) of a board (fp16, exact); two buffers: board parity
+    // layer-1 input, aggregated FIRST: G'[n][f] = sum over the closed neighbourhood k of n of X0[k][f] / sqrt(deg k), as fp16
+    // hi[0..7] | lo[8..15] per node (6 features used, slots 6, 7 stay zero); two buffers: board parity (the next board's rows are
+    // written while this board's layers 2, 3 run)
+    alignas(16) unsigned short G16[2][81][16];
+    alignas(16) float Y[NWV][96];                      // per-wave scratch of the setup: X0[k][f] / sqrt(deg k) of the wave's feature
     alignas(16) unsigned short degv[NWV][NWV == 4 ? 3 : 2][32];   // per wave and block slot: fp16 CQ / deg of the 32 nodes of a k block
 };
 static_assert(2 * sizeof(TrunkSmemM<8>) <= 160 * 1024, "two 8-wave workgroups per CU");
@@ -777,14 +788,14 @@ __device__ __forceinline__ void request_bias(f32x4 (&out)[6][JT], __amdgpu_buffe
 // tile nt + 1 is still on the matrix pipe: its relu / split / stores are vector and LDS work issued under those MFMAs.
 // (No plane byte is read here: the caller has passed the barrier behind the linear map, the stores are free to go.)
 template <int JT, bool LAST>
-__device__ __forceinline__ void aggregate_store(TrunkSmemM<8 / JT>& sm, u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], f32x4 (&out)[6][JT], int wave, int lane,
-                                                __amdgpu_buffer_rsrc_t pooled_rs, int pooled_soff, float* pooled_lds = nullptr) {
+__device__ __forceinline__ void aggregate_store(TrunkSmemM<8 / JT>& sm, const unsigned int (&AF)[AF_BLOCKS][64][4], u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], f32x4 (&out)[6][JT], int wave, int lane,
+                                                const int (&toff)[3], __amdgpu_buffer_rsrc_t pooled_rs, int pooled_soff, float* pooled_lds = nullptr) {
     constexpr int AHEAD = 3;                                   // adjacency fragments in flight (4 registers each)
     const int c = lane & 15, q = lane >> 4;
     const int col0 = 16 * JT * wave + 4 * q;
     u32x4 af[AF_BLOCKS];
 #pragma unroll
-    for (int i = 0; i < AHEAD; ++i) af[i] = *reinterpret_cast<const u32x4*>(&sm.AF[i][lane][0]);
+    for (int i = 0; i < AHEAD; ++i) af[i] = *reinterpret_cast<const u32x4*>(&AF[i][lane][0]);
 #pragma unroll
     for (int j = 0; j < JT; ++j) split_fence(zl[j][0], zl[j][1], zl[j][2]);
     f32x4 sum[JT];
@@ -794,7 +805,7 @@ __device__ __forceinline__ void aggregate_store(TrunkSmemM<8 / JT>& sm, u32x4 (&
         const int node = 16 * nt + c;
         const bool live = (nt < 5) || (c == 0);                              // node < 81
         float dn = 0.f;
-        if (LAST) dn = sm.dnv[node];
+        if (LAST) dn = dinv_of_dm(((unsigned)toff[nt >> 1] >> (9 + 16 * (nt & 1))) & 7u);    // deg - 1 sits above the row offset's 9 bits
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             f32x4 v = out[nt][j];
@@ -816,7 +827,7 @@ __device__ __forceinline__ void aggregate_store(TrunkSmemM<8 / JT>& sm, u32x4 (&
 #pragma unroll
     for (int blk = 0; blk < AF_BLOCKS; ++blk) {
         const int kb = af_kb(blk), nt = af_nt(blk);
-        if (blk + AHEAD < AF_BLOCKS) af[blk + AHEAD] = *reinterpret_cast<const u32x4*>(&sm.AF[blk + AHEAD][lane][0]);
+        if (blk + AHEAD < AF_BLOCKS) af[blk + AHEAD] = *reinterpret_cast<const u32x4*>(&AF[blk + AHEAD][lane][0]);
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             out[nt][j] = mfma_f16(zl[j][kb], af[blk], out[nt][j]);
@@ -838,6 +849,56 @@ __device__ __forceinline__ void aggregate_store(TrunkSmemM<8 / JT>& sm, u32x4 (&
             // (buffer store off an SGPR descriptor + scalar row offset: no 64-bit address registers alive across the board loop)
             if (c == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), pooled_rs, (col0 + 16 * j) * 4, pooled_soff, 0);
             if (pooled_lds && c == 0) *reinterpret_cast<f32x4*>(pooled_lds + col0 + 16 * j) = t;
+        }
+    }
+}
+
+// Bit `lane` of a wave-uniform 64-bit mask, as 0 / 1 or as 0 / a: ONE v_cndmask with the scalar pair as its lane condition
+// (what `(m >> lane) & 1` means, minus the 64-bit vector shift).  The masks are SALU results: no VALU-SGPR hazard to pad.
+// (readfirstlane: the register allocator must see a scalar pair even where it chose vector registers for a uniform value; it
+// folds away when the value already is one.)
+__device__ __forceinline__ uint64_t uniform64(uint64_t m) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32);
+}
+__device__ __forceinline__ uint32_t lane_bit(uint64_t m) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(uniform64(m)));
+    return r;
+}
+__device__ __forceinline__ float lane_sel(uint64_t m, float a) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(uniform64(m)));
+    return r;
+}
+
+// Layer 1, aggregate-first:  Q1^T = relu( (c W1) G'^T + c sqrt(deg) b )  -- ONE MFMA per node tile and feature tile.  A = the wave's
+// W1 fragment (rows = its 16 output features; k = the six input features three times: hi.hi, hi.lo, lo.hi), B = the node tile's
+// rows of G' (lane = node; k-slots of q = 0 / 2 read the hi half, q = 1 the lo half, q = 3 meets zero weight slots), accumulated on
+// the bias rows.  The result already has the store layout (lane = node, 4 consecutive features): relu, fp16 split, plane stores.
+// 6 MFMAs per wave and feature tile where the linear-first form needed 6 + 20 (X0 W1, then the 128-wide banded aggregation).
+template <int JT>
+__device__ __forceinline__ void layer1_store(TrunkSmemM<8 / JT>& sm, const unsigned short (&G)[81][16], const u32x4 (&w1f)[JT], f32x4 (&out)[6][JT],
+                                             int wave, int lane) {
+    const int c = lane & 15, q = lane >> 4;
+    const int col0 = 16 * JT * wave + 4 * q;
+    u32x4 gf[6];
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) gf[nt] = *reinterpret_cast<const u32x4*>(&G[nt < 5 ? 16 * nt + c : 80][8 * (q & 1)]);
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) out[nt][j] = mfma_f16(w1f[j], gf[nt], out[nt][j]);
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) {
+        const int node = 16 * nt + c;
+        const bool live = (nt < 5) || (c == 0);                              // node < 81
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            f32x4 v = out[nt][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = relu_sat16(v[e]);
+            if (live) store_split4(sm, plane_off(node, (col0 + 16 * j) >> 3) + ((2 * (col0 + 16 * j)) & 15), v);
         }
     }
 }
@@ -964,6 +1025,16 @@ __device__ __forceinline__ void fused_heads_512(FusedHeadsScratch& sc, __amdgpu_
     }
 }
 
+// Where a board's inputs are built (developer switches, A/B'd with tools/ab_trunk.py):
+//   AQG_PREFETCH 1: board b + 1's inputs are built under board b's layer 3 into the other buffers (no setup phase per board);
+//                0: at the top of each board.   AQG_AF_AT 0: adjacency fragments together with the G' rows; 1: after layer 1;
+//                2: after the layer-2 linear map, in front of the barrier its early waves wait at anyway.
+#ifndef AQG_PREFETCH
+#define AQG_PREFETCH 0
+#endif
+#ifndef AQG_AF_AT
+#define AQG_AF_AT 1
+#endif
 // (hipcc's second launch-bound argument is waves per SIMD: workgroups per CU x waves per workgroup / 4 SIMDs)
 template <int JT, int WGS_PER_CU, bool FUSE = false>
 __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trunk_boards_mm_kernel(const void* __restrict__ states, int fmt, int B,
@@ -1033,42 +1104,103 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
             if (b < B) fetch_record(b, rec0, rec1);
         }
     }
-    // once per workgroup: the padding rows no board ever writes.  No barrier here: their first reader sits behind the
-    // first board's setup barrier.
-    if (wave0 == 0) { const int l0 = fresh_lane(); if (l0 < 15) { sm.sqd[81 + l0] = 0.f; sm.dnv[81 + l0] = 0.f; } }
+    // once per workgroup: the k-slots 6, 7 of the hi and lo halves of every G' row, which no board ever writes.  No barrier here:
+    // their first reader sits behind the first board's setup barrier.
+    {
+        const int t0 = (int)threadIdx.x;
+        for (int i = t0; i < 2 * 81 * 2; i += 64 * NWV)
+            *reinterpret_cast<unsigned int*>(&sm.G16[0][0][0] + 16 * (i >> 1) + 6 + 8 * (i & 1)) = 0u;
+    }
     u32x4 Bf[2][JT][4];
     const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pooled, 0, B * (HID * 4), 0x00020000);
 
-    AQG_STAMP_DECL
-    while (b < B) {
-        AQG_STAMP_AT(7)
-        wave = wave0;
-        asm volatile("" : "+s"(wave));         // opaque per board: wave-derived predicates are recomputed (2-3 scalar ops), not
-                                               // hoisted out of the loop into registers that then spill
-        const int lane = fresh_lane(), tid = 64 * wave + lane, c = lane & 15, q = lane >> 4;
-        // the small layer-1 weight fragment goes out first (lands under the setup)
-        u32x4 w1f[JT];
-#pragma unroll
-        for (int j = 0; j < JT; ++j) w1f[j] = load_frag16(rs, lane * 16, (int)(PackedLayout::WH1 * sizeof(float)) + (wave * JT + j) * (64 * 16));
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- setup.  The record becomes wave-uniform scalars (the wall masks by ballot over the 64 wall bytes), the
-        //      open-edge bitboards are computed once per wave on the scalar unit, lanes only extract their bits.
+    // ---- per-board inputs.  decode: the record becomes wave-uniform scalars (the wall masks by ballot over the 64 wall bytes).
+    auto decode = [&](uint32_t r0, uint32_t r1, uint64_t& hw, uint64_t& vw, uint32_t& hd) {
+        if (fmt == 0) {
+            hw = __ballot((r0 & 1u) != 0);                               // wall byte: bit0 H, bit1 V
+            vw = __ballot((r0 & 2u) != 0);
+            hd = __builtin_amdgcn_readfirstlane(r1);
+        } else {
+            // (readlane returns a SIGNED int: without the uint32_t cast a wall in slot 31 sign-extends into slots 32..63 --
+            //  a round-1 bug that only the in-engine evaluation path could hit; tests/test_gpu_parity.py pins it now)
+            hw = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(r0, 0) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(r0, 1) << 32);
+            vw = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(r0, 2) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(r0, 3) << 32);
+            hd = (uint32_t)__builtin_amdgcn_readlane(r0, 4);
+        }
+    };
+    // deg - 1 = U + D + L + R of every node as three bit planes (bit-sliced adder on the scalar unit; c1 excludes c3, so
+    // c1 + c2 + c3 <= 2 and b2 = c1 & c2), lo = nodes 0..63, hi = nodes 64..80
+    struct Planes { uint64_t b0l, b1l, b2l, b0h, b1h, b2h; };
+    auto degree_planes = [](const Open& op) -> Planes {
+        Planes p;
         {
-            uint64_t hw, vw;
-            uint32_t hd;
-            if (fmt == 0) {
-                hw = __ballot((rec0 & 1u) != 0);                             // wall byte: bit0 H, bit1 V
-                vw = __ballot((rec0 & 2u) != 0);
-                hd = __builtin_amdgcn_readfirstlane(rec1);
-            } else {
-                // (readlane returns a SIGNED int: without the uint32_t cast a wall in slot 31 sign-extends into slots 32..63 --
-                //  a round-1 bug that only the in-engine evaluation path could hit; tests/test_gpu_parity.py pins it now)
-                hw = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(rec0, 0) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(rec0, 1) << 32);
-                vw = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(rec0, 2) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(rec0, 3) << 32);
-                hd = (uint32_t)__builtin_amdgcn_readlane(rec0, 4);
+            const uint64_t x = op.U.lo ^ op.D.lo, c1 = op.U.lo & op.D.lo, y = op.L.lo ^ op.R.lo, c2 = op.L.lo & op.R.lo, c3 = x & y;
+            p.b0l = x ^ y; p.b1l = c1 ^ c2 ^ c3; p.b2l = c1 & c2;
+        }
+        {
+            const uint64_t x = op.U.hi ^ op.D.hi, c1 = op.U.hi & op.D.hi, y = op.L.hi ^ op.R.hi, c2 = op.L.hi & op.R.hi, c3 = x & y;
+            p.b0h = x ^ y; p.b1h = c1 ^ c2 ^ c3; p.b2h = c1 & c2;
+        }
+        return p;
+    };
+    // build_inputs: everything a board's layers read from LDS besides the planes, into buffer `par` --
+    //  (1) layer-1 input, aggregated first (GCNConv is linear before its ReLU: A_hat (X W) = (A_hat X) W, and X has 6 columns where
+    //      X W has 128):  G'[n][f] = sum_{k in N[n]} X0[k][f] / sqrt(deg k)  (the 1 / sqrt(deg n) half of the symmetric norm cancels
+    //      against the sqrt(deg) scale of the plane image).  Wave f < 6 owns feature f for all 81 nodes (lane = node `lane`, lanes
+    //      < 17 also node 64 + lane): the feature is a wave-uniform bitboard times a scalar (pv_network_cnn.py:88-114: pawn tile,
+    //      walls in hand, enemy pawn tile in the enemy's frame, its walls, horizontal / vertical wall at the tile's slot), so x = one
+    //      v_cndmask; x / sqrt(deg) goes through 384 bytes of the wave's own LDS scratch to reach the four neighbours (no other
+    //      wave is involved: no barrier), the sum is split into fp16 hi / lo and stored as the B operand rows of layer 1;
+    //  (2) the banded adjacency fragments of layers 2 and 3.
+    // Called for the first board of a workgroup before the loop, and for board b + 1 under board b's layer 3 (the buffers of the
+    // other parity were last read a whole board ago: four barriers back).
+    auto build_inputs = [&](int par, uint64_t hw, uint64_t vw, uint32_t hd, int what) {
+        const Open op = make_open<N>(hw, vw);
+        const Planes pl = degree_planes(op);
+        if (what & 1) {
+            const int ppos = hd & 0xff, pwl = (hd >> 8) & 0xff, epos = (hd >> 16) & 0xff, ewl = hd >> 24;
+            const BB shb = spread_slots<N>(hw), svb = spread_slots<N>(vw);
+#pragma unroll
+            for (int it = 0; it < (6 + NWV - 1) / NWV; ++it) {
+                const int f = __builtin_amdgcn_readfirstlane(wave + NWV * it);   // wave-uniform, and known to be: the masks below stay scalar
+                if (f < 6) {
+                    BB m = mask_all<N>();
+                    float sc = 1.f;
+                    if (f == 0) m = bb_bit(ppos);
+                    else if (f == 1) sc = (float)pwl;
+                    else if (f == 2) m = bb_bit(epos);
+                    else if (f == 3) sc = (float)ewl;
+                    else if (f == 4) m = shb;
+                    else m = svb;
+                    const int ln = fresh_lane(), l1 = min(ln, 16);
+                    const float dnv0 = dinv_of_dm(lane_bit(pl.b0l) | (lane_bit(pl.b1l) << 1) | (lane_bit(pl.b2l) << 2));
+                    const float dnv1 = dinv_of_dm(lane_bit(pl.b0h) | (lane_bit(pl.b1h) << 1) | (lane_bit(pl.b2h) << 2));
+                    const float y0 = lane_sel(m.lo, sc) * dnv0, y1 = lane_sel(m.hi, sc) * dnv1;
+                    float* Yw = sm.Y[wave];
+                    Yw[ln] = y0;
+                    if (ln < 17) Yw[64 + ln] = y1;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // (an edge that is open leads to a node of the board: clamped addresses are only ever read by lanes that discard them)
+                    const float nu0 = Yw[max(ln - 9, 0)], nd0 = Yw[ln + 9], nl0 = Yw[max(ln - 1, 0)], nr0 = Yw[ln + 1];
+                    const float nu1 = Yw[55 + l1], nd1 = Yw[73 + l1], nl1 = Yw[63 + l1], nr1 = Yw[65 + l1];
+                    const float g0 = (((y0 + lane_sel(op.U.lo, nu0)) + lane_sel(op.D.lo, nd0)) + lane_sel(op.L.lo, nl0)) + lane_sel(op.R.lo, nr0);
+                    const float g1 = (((y1 + lane_sel(op.U.hi, nu1)) + lane_sel(op.D.hi, nd1)) + lane_sel(op.L.hi, nl1)) + lane_sel(op.R.hi, nr1);
+                    const _Float16 h0 = (_Float16)g0, h1 = (_Float16)g1;
+                    const _Float16 e0 = (_Float16)(g0 - (float)h0), e1 = (_Float16)(g1 - (float)h1);
+                    sm.G16[par][ln][f] = __builtin_bit_cast(unsigned short, h0);
+                    sm.G16[par][ln][8 + f] = __builtin_bit_cast(unsigned short, e0);
+                    if (ln < 17) {
+                        sm.G16[par][64 + ln][f] = __builtin_bit_cast(unsigned short, h1);
+                        sm.G16[par][64 + ln][8 + f] = __builtin_bit_cast(unsigned short, e1);
+                    }
+                }
             }
-            const Open op = make_open<N>(hw, vw);
+        }
+        if (what & 2) {
+            const int lane = fresh_lane();
             // the four open-edge boards as 3 x 32-bit words each (word w = nodes 32 w .. 32 w + 31), selected arithmetically
             // (scalars, not an array: an indexed local array would live in scratch memory)
             const uint32_t u0 = (uint32_t)op.U.lo, u1 = (uint32_t)(op.U.lo >> 32), u2 = (uint32_t)op.U.hi;
@@ -1079,27 +1211,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
             auto open_word = [&](int dir, int w) -> uint32_t {
                 return dir == 0 ? sel3(u0, u1, u2, w) : dir == 1 ? sel3(d0w, d1w, d2w, w) : dir == 2 ? sel3(l0, l1, l2, w) : sel3(r0w, r1w, r2w, w);
             };
-            if (tid < V) {
-                int t = tid;
-                asm volatile("" : "+v"(t));   // opaque per iteration: nothing per-tile is hoisted out of the board loop
-                const int x = (t * 57) >> 9, y = t - 9 * x;                 // t / 9, t % 9 for t < 81
-                const int ppos = hd & 0xff, pwl = (hd >> 8) & 0xff, epos = (hd >> 16) & 0xff, ewl = hd >> 24;
-                const bool slot_ok = (x < S) && (y < S);
-                const int slot = (x * S + y) & 63;
-                u32x4 xr;                                                    // all six features are small integers: exact in fp16
-                xr[0] = cvt_pk_f16((t == ppos) ? 1.f : 0.f, (float)pwl);
-                xr[1] = cvt_pk_f16((t == epos) ? 1.f : 0.f, (float)ewl);
-                xr[2] = cvt_pk_f16((slot_ok && bit_of64(hw, slot)) ? 1.f : 0.f, (slot_ok && bit_of64(vw, slot)) ? 1.f : 0.f);
-                xr[3] = 0u;
-                *reinterpret_cast<u32x4*>(&sm.X0[t][0]) = xr;
-                const int w = t >> 5, sft = t & 31;
-                const uint32_t deg = 1u + ((open_word(0, w) >> sft) & 1u) + ((open_word(1, w) >> sft) & 1u) +
-                                     ((open_word(2, w) >> sft) & 1u) + ((open_word(3, w) >> sft) & 1u);
-                sm.dnv[t] = dinv_of((int)deg);
-                sm.sqd[t] = deg == 1u ? 1.0f : deg == 2u ? 1.41421356237309505f : deg == 3u ? 1.73205080756887729f : deg == 4u ? 2.0f : 2.23606797749978970f;
-            }
-            // ten adjacency blocks over the waves, the two waves that also write X0 / sqd / dnv getting the fewest:
-            //   8 waves: w0 {8}  w1 {9}  w2 {0,6}  w3 {1,7}  w4..7 {2..5}      4 waves: w0 {0,4}  w1 {1,5}  w2 {2,6,8}  w3 {3,7,9}
+            // ten adjacency blocks over the waves:   8 waves: w0 {8}  w1 {9}  w2 {0,6}  w3 {1,7}  w4..7 {2..5}      4 waves: w0 {0,4}  w1 {1,5}  w2 {2,6,8}  w3 {3,7,9}
             auto slot_block = [&](int it) -> int {                           // wave-uniform
                 if (NWV == 8) return it == 0 ? (wave >= 2 ? wave - 2 : wave + 8) : ((wave == 2 || wave == 3) ? wave + 4 : AF_BLOCKS);
                 return it < 2 ? wave + 4 * it : (wave >= 2 ? wave + 6 : AF_BLOCKS);
@@ -1149,48 +1261,66 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
                             fr[2 * h + 1] = (((t2 >> 2) & 0x00010001u) * 0xFFFFu) & dv[1];
                         }
                     }
-                    *reinterpret_cast<u32x4*>(&sm.AF[blk][ln][0]) = fr;
+                    *reinterpret_cast<u32x4*>(&sm.AF[par][blk][ln][0]) = fr;
                 }
             }
         }
-        int bn = b + gridDim.x;
-        while (bn < B && active && !active[bn]) bn += gridDim.x;
-        __syncthreads();
-        AQG_STAMP_AT(0)
-        phase_prio(1);
-        // byte offset of this lane's rows in a bias table, (deg - 1) * 512 + 16 q with deg = round(sqd^2) (first row for the
-        // padding nodes), two node tiles per register
-        int toff[3];
+    };
+
+    AQG_STAMP_DECL
+    int par = 0;
+    bool first = true;
+    while (b < B) {
+        AQG_STAMP_AT(7)
+        wave = wave0;
+        asm volatile("" : "+s"(wave));         // opaque per board: wave-derived predicates are recomputed (2-3 scalar ops), not
+                                               // hoisted out of the loop into registers that then spill
+        asm volatile("" : "+s"(par));
+        const int lane = fresh_lane(), c = lane & 15, q = lane >> 4;
+        // the small layer-1 weight fragment goes out first
+        u32x4 w1f[JT];
 #pragma unroll
-        for (int nt = 0; nt < 6; ++nt) {
-            const float sq = sm.sqd[16 * nt + c];
-            const int o = max((int)(sq * sq + 0.5f) - 1, 0) * (HID * 4) + 16 * q;
-            toff[nt >> 1] = (nt & 1) ? (toff[nt >> 1] | (o << 16)) : o;
+        for (int j = 0; j < JT; ++j) w1f[j] = load_frag16(rs, lane * 16, (int)(PackedLayout::WH1 * sizeof(float)) + (wave * JT + j) * (64 * 16));
+        __builtin_amdgcn_sched_barrier(0);
+        // byte offset of this lane's rows in a bias table, (deg - 1) * 512 + 16 q, for its node 16 nt + c of every node tile (first
+        // row for the padding nodes 81..95: their plane bits are zero), two node tiles per register; deg - 1 stays readable above
+        // bit 9 (the mean pool's 1 / sqrt(deg)).  Straight from the record's bit planes: nothing here waits for a barrier.
+        int toff[3];
+        uint64_t hw, vw;
+        uint32_t hd;
+        decode(rec0, rec1, hw, vw, hd);
+        {
+            const Planes pl = degree_planes(make_open<N>(hw, vw));
+#pragma unroll
+            for (int nt = 0; nt < 6; ++nt) {
+                const uint32_t w0 = nt < 4 ? (uint32_t)(pl.b0l >> (32 * (nt >> 1))) : (uint32_t)pl.b0h;
+                const uint32_t w1 = nt < 4 ? (uint32_t)(pl.b1l >> (32 * (nt >> 1))) : (uint32_t)pl.b1h;
+                const uint32_t w2 = nt < 4 ? (uint32_t)(pl.b2l >> (32 * (nt >> 1))) : (uint32_t)pl.b2h;
+                const int sft = (nt < 4 ? 16 * (nt & 1) : 16 * (nt - 4)) + c;
+                const int dm = (int)(((w0 >> sft) & 1u) | (((w1 >> sft) & 1u) << 1) | (((w2 >> sft) & 1u) << 2));
+                const int o = dm * (HID * 4) + 16 * q;
+                toff[nt >> 1] = (nt & 1) ? (toff[nt >> 1] | (o << 16)) : o;
+            }
         }
         f32x4 out[6][JT];
         u32x4 zh[JT][3], zl[JT][3];
-        // ---- layer 1: U = sqrt(deg) (.) (X0 W1) (one MFMA per tile), aggregation, planes
-        request_bias<JT>(out, rs, 0, toff, wave);
-#pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            // (lanes q >= 2 meet zero rows of the weight fragment: their copy of the features contributes nothing)
-            const u32x4 xf = *reinterpret_cast<const u32x4*>(&sm.X0[m < 5 ? 16 * m + c : 80][0]);
-            const f32x4 sq4 = *reinterpret_cast<const f32x4*>(&sm.sqd[16 * m + 4 * q]);   // 0 beyond node 80: clears tile 5's duplicate rows
-#pragma unroll
-            for (int j = 0; j < JT; ++j) {
-                const f32x4 u = mfma_f16(xf, w1f[j], (f32x4){0.f, 0.f, 0.f, 0.f}) * sq4;
-#pragma unroll
-                for (int piece = 0; piece < 3; ++piece) split_tile_piece(u, m, piece, zh[j], zl[j]);
-            }
-        }
+        request_bias<JT>(out, rs, 0, toff, wave);                            // lands under the input build + barrier
+        AQG_STAMP_AT(6)
+        if (!AQG_PREFETCH || first) build_inputs(par, hw, vw, hd, AQG_AF_AT == 0 ? 3 : 1);
+        int bn = b + gridDim.x;
+        while (bn < B && active && !active[bn]) bn += gridDim.x;
+        __syncthreads();                     // this board's G' rows and adjacency fragments are complete; the previous board is done
+        AQG_STAMP_AT(0)
+        phase_prio(1);
+        // ---- layer 1: one MFMA per node tile on top of the bias rows, relu, planes
+        layer1_store<JT>(sm, sm.G16[par], w1f, out, wave, lane);
         AQG_STAMP_AT(8)
         __builtin_amdgcn_sched_barrier(0);
-        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights: land under the aggregation + barrier
+        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights: land under the barrier
         __builtin_amdgcn_sched_barrier(0);
         phase_prio(2);
-        aggregate_store<JT, false>(sm, zh, zl, out, wave, lane, prs, 0);     // (nobody reads the planes now: stores need no barrier)
+        if (AQG_AF_AT == 1) build_inputs(par, hw, vw, hd, 2);
         AQG_STAMP_AT(9)
-        AQG_STAMP_AT(10)
         __syncthreads();
         AQG_STAMP_AT(1)
         // ---- layer 2
@@ -1198,6 +1328,9 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         request_bias<JT>(out, rs, 1, toff, wave);
         linear_split<JT>(sm, Bf, lane, zh, zl);
         AQG_STAMP_AT(2)
+        // the adjacency fragments, here: the layer-2 weight fragments are dead (32 registers free), the layer-3 ones not yet
+        // requested, and the waves that finish the linear map first wait at the next barrier anyway
+        if (AQG_AF_AT == 2) build_inputs(par, hw, vw, hd, 2);
         AQG_STAMP_AT(11)
         __builtin_amdgcn_sched_barrier(0);
         load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH3, wave, lane);             // lands under the barrier + aggregation
@@ -1208,13 +1341,22 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         __syncthreads();                                                    // every wave is done reading the planes
         AQG_STAMP_AT(13)
         phase_prio(4);
-        aggregate_store<JT, false>(sm, zh, zl, out, wave, lane, prs, 0);
+        aggregate_store<JT, false>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, 0);
         AQG_STAMP_AT(14)
         __syncthreads();
         AQG_STAMP_AT(3)
         // ---- layer 3 + mean pool
         phase_prio(5);
         request_bias<JT>(out, rs, 2, toff, wave);
+        if (AQG_PREFETCH && bn < B) {
+            // the NEXT board's G' rows and adjacency fragments, into the other buffers: vector / scalar / LDS work that the two
+            // resident workgroups' matrix phases cover, instead of a setup phase in front of every board
+            uint64_t hw, vw;
+            uint32_t hd;
+            decode(nrec0, nrec1, hw, vw, hd);
+            build_inputs(par ^ 1, hw, vw, hd, AQG_AF_AT == 0 ? 3 : 1);
+        }
+        AQG_STAMP_AT(10)
         linear_split<JT>(sm, Bf, lane, zh, zl);
         AQG_STAMP_AT(4)
         AQG_STAMP_AT(15)
@@ -1222,17 +1364,20 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
             // the board's heads, right here: the plane image is dead once every wave is past its layer-3 linear map (the barrier)
             FusedHeadsScratch& hs = *reinterpret_cast<FusedHeadsScratch*>(&sm.P[0][0]);
             __syncthreads();
-            aggregate_store<JT, true>(sm, zh, zl, out, wave, lane, prs, b * (HID * 4), hs.g);
+            aggregate_store<JT, true>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, b * (HID * 4), hs.g);
             __syncthreads();
+            const int tid = 64 * wave + lane;
             fused_heads_512(hs, rs, pk, A, tid, logits ? logits + (size_t)b * A : nullptr, policy ? policy + (size_t)b * A : nullptr,
                             value_pre ? value_pre + b : nullptr, value ? value + b : nullptr);
         } else {
             phase_prio(6);
-            aggregate_store<JT, true>(sm, zh, zl, out, wave, lane, prs, b * (HID * 4));
+            aggregate_store<JT, true>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, b * (HID * 4));
         }
         rec0 = nrec0; rec1 = nrec1;
-        if (bn < B) __syncthreads();                                        // AF / X0 / sqd / dnv / planes are free for the next board
-                                                                            // (bn is workgroup-uniform; the last board needs no barrier)
+        if (AQG_PREFETCH) par ^= 1;
+        else if (bn < B) __syncthreads();     // single buffers: every wave is done with this board's G' rows / fragments / planes
+        first = false;
+        // (no barrier here: the next board's first writes -- its planes, in layer 1 -- sit behind the barrier at the top of the loop)
         AQG_STAMP_AT(5)
 #ifdef AQG_STAMP
         ++st_n;

@@ -247,12 +247,12 @@ class GNNNetwork(GraphPolicyValueNetwork):
 
     def prep_for_inference(self, model_path):
         """BaseNetwork.py:21-32 minus the TensorRT compile."""
-        device = "cuda" if torch.cuda.is_available() else "cpu"
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self.load_state_dict(torch.load(model_path, map_location=device, weights_only=True))
         self.eval()
         self.to(device)
-        if device == "cuda":
-            self.packed_weights(torch.device("cuda", torch.cuda.current_device()))
+        if device.type == "cuda":
+            self.packed_weights(device)
 
     def preprocess_input(self, game_state_arrays):
         """List of State.to_array() triples -> uint8 [n,72] state records (the input the GNN kernels accept).

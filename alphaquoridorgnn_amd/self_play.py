@@ -12,6 +12,7 @@ from datetime import datetime
 import numpy as np
 import torch
 
+from . import distributed as aqd
 from . import pv_mcts
 from .constants import PV_NETWORK_PATH, BOARD_SIZE
 from .engine import BatchedSelfPlay, MultiSetSelfPlay, gather_history
@@ -70,8 +71,7 @@ def _fresh_seed():
     env = os.environ.get("AQG_SELFPLAY_SEED")
     seed = int(env) if env is not None else int(np.random.randint(0, 2 ** 31 - 1))
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
-        t = torch.tensor([seed], dtype=torch.int64, device=dev)
+        t = torch.tensor([seed], dtype=torch.int64, device=aqd.collective_device())
         dist.broadcast(t, src=0)
         seed = int(t.item())
     return seed
@@ -89,13 +89,14 @@ def self_play(model=None, games=None, seed=None):
     rank, world = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
     base = _fresh_seed() if seed is None else int(seed)
     mine = total // world + (1 if rank < total % world else 0)
-    st = torch.zeros((0, 72), dtype=torch.uint8, device='cuda')
-    vis = torch.zeros((0, POLICY_OUTPUT_SIZE), dtype=torch.int16, device='cuda')
-    z = torch.zeros((0,), dtype=torch.int8, device='cuda')
+    dev = aqd.device()                                   # this rank's GPU (LOCAL_RANK under torchrun), never a bare 'cuda'
+    st = torch.zeros((0, 72), dtype=torch.uint8, device=dev)
+    vis = torch.zeros((0, POLICY_OUTPUT_SIZE), dtype=torch.int16, device=dev)
+    z = torch.zeros((0,), dtype=torch.int8, device=dev)
     if mine > 0:
         # >= 256 games: independent game sets on their own streams fill the holes of each other's serial kernel chains
         eng = MultiSetSelfPlay(model, num_games=mine, sims=pv_mcts.PV_EVALUATE_COUNT, num_sets=None if mine >= 256 else 1,
-                               board_size=BOARD_SIZE, temperature=SP_TEMPERATURE, seed=(base + rank) % (2 ** 31 - 1))
+                               board_size=BOARD_SIZE, temperature=SP_TEMPERATURE, seed=(base + rank) % (2 ** 31 - 1), device=dev)
         c = eng.play_generation()
         print(f'\rSelf-play (rank {rank}: {c["finished"]}/{mine} games)', end='')
         st, vis, z = eng.history_tensors()
@@ -114,5 +115,24 @@ def self_play(model=None, games=None, seed=None):
     return path
 
 
+def main(argv=None):
+    """`python -m alphaquoridorgnn_amd.self_play` -- also the per-rank program of
+    `python -m torch.distributed.run --nproc-per-node N ... -m alphaquoridorgnn_amd.self_play` (distributed.init_from_env binds
+    the rank to its GPU and joins the group; one generation sharded over the ranks, one all-gather, rank 0 writes the file)."""
+    import argparse
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--games", type=int, default=None, help="games of the generation over ALL ranks (default SP_GAME_COUNT)")
+    ap.add_argument("--sims", type=int, default=None, help="simulations per move (default pv_mcts.PV_EVALUATE_COUNT)")
+    ap.add_argument("--seed", type=int, default=None, help="fix the uniform streams (default: fresh per call, like the reference)")
+    args = ap.parse_args(argv)
+    aqd.init_from_env()
+    if args.sims is not None:
+        pv_mcts.PV_EVALUATE_COUNT = args.sims
+    try:
+        return self_play(games=args.games, seed=args.seed)
+    finally:
+        aqd.shutdown()
+
+
 if __name__ == '__main__':
-    self_play()
+    main()

@@ -5,6 +5,7 @@
 (The reference's commented-out evaluate_best_player stage -- CPU baseline agents, SURVEY 8f.4 -- is not part of this build.)
 """
 from . import constants
+from . import distributed as aqd
 from .evaluate_network import evaluate_network
 from .pv_network_gnn import create_network
 from .self_play import self_play
@@ -36,9 +37,15 @@ def _evaluate_once():
     is broadcast, and nobody reads best.pth again before the copy is done."""
     import torch
     dist, on, rank = _dist()
-    promoted = evaluate_network() if rank == 0 else False
+    tag = aqd.next_tag("evaluate")
+    if rank == 0:
+        promoted = evaluate_network()
+        aqd.release_ranks(tag)
+    else:
+        promoted = False
+        aqd.wait_for_rank0(tag)          # host-side wait: no collective is pending while rank 0 plays the match
     if on:
-        t = torch.tensor([1 if promoted else 0], dtype=torch.int64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+        t = torch.tensor([1 if promoted else 0], dtype=torch.int64, device=aqd.collective_device())
         dist.broadcast(t, src=0)
         promoted = bool(int(t.item()))
         dist.barrier()
@@ -62,5 +69,46 @@ def train_cycle(num_cycles=None):
     return promoted
 
 
+def main(argv=None):
+    """`python -m alphaquoridorgnn_amd.train_cycle` -- also the per-rank program of
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P -m
+    alphaquoridorgnn_amd.train_cycle`: every rank binds to GPU LOCAL_RANK and joins the RCCL group (distributed.init_from_env)
+    before anything touches a device; self-play is sharded over the ranks, rank 0 trains / evaluates (module docstrings)."""
+    import argparse
+    import json
+    import os
+    from . import evaluate_network as en, pv_mcts, self_play as sp, train_network as tn
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--cycles", type=int, default=None, help="training cycles (default NUM_TRAIN_CYCLE = 1000, train_cycle.py:18)")
+    ap.add_argument("--games", type=int, default=None, help="self-play games per generation over ALL ranks (default SP_GAME_COUNT)")
+    ap.add_argument("--sims", type=int, default=None, help="simulations per move (default pv_mcts.PV_EVALUATE_COUNT)")
+    ap.add_argument("--epochs", type=int, default=None, help="epochs per parameter update (default train_network.NUM_EPOCH)")
+    ap.add_argument("--eval-games", type=int, default=None, help="games per evaluation (default EN_GAME_COUNT)")
+    ap.add_argument("--result-dir", default=None, help="every rank writes train_cycle.rank<r>.json (promotions, sha256 of latest.pth) here")
+    args = ap.parse_args(argv)
+    rank, world = aqd.init_from_env()
+    if args.games is not None:
+        sp.SP_GAME_COUNT = args.games
+    if args.sims is not None:
+        pv_mcts.PV_EVALUATE_COUNT = args.sims
+    if args.epochs is not None:
+        tn.NUM_EPOCH = args.epochs
+    if args.eval_games is not None:
+        en.EN_GAME_COUNT = args.eval_games
+    try:
+        promoted = train_cycle(args.cycles)
+        if args.result_dir:
+            import hashlib
+            with open(constants.PV_NETWORK_PATH + 'latest.pth', 'rb') as f:
+                digest = hashlib.sha256(f.read()).hexdigest()
+            import torch
+            with open(os.path.join(args.result_dir, f"train_cycle.rank{rank}.json"), "w") as f:
+                json.dump({"rank": rank, "world": world, "promoted": promoted, "latest_sha256": digest,
+                           "device": torch.cuda.current_device()}, f)
+        return promoted
+    finally:
+        aqd.shutdown()
+
+
 if __name__ == '__main__':
-    train_cycle()
+    main()

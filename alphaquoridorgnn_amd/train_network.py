@@ -169,8 +169,14 @@ def train_network():
     import torch.distributed as dist
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
     if world > 1 and os.environ.get("AQG_TRAIN_DATA_PARALLEL", "0") != "1":
+        from . import distributed as aqd
+        tag = aqd.next_tag("train")
         if rank == 0:
             _train_single_process()
+            aqd.release_ranks(tag)
+        else:
+            aqd.wait_for_rank0(tag)     # host-side wait on the rendezvous store: no collective is pending while rank 0 trains, so
+                                        # the stage may outlast the process group's watchdog timeout (distributed.py)
         dist.barrier()          # latest.pth is complete before any rank moves on to the evaluation stage
         return
     _train_loop(rank, world)
@@ -182,31 +188,33 @@ def _train_single_process():
 
 def _train_loop(rank, world):
     import torch.distributed as dist
+    from . import distributed as aqd
+    dev = aqd.device()                                                             # this rank's GPU, explicitly
     model = GNNNetwork()
-    model.load_state_dict(torch.load(PV_NETWORK_PATH + 'best.pth', map_location='cuda', weights_only=True))
-    model = model.to('cuda')
+    model.load_state_dict(torch.load(PV_NETWORK_PATH + 'best.pth', map_location=dev, weights_only=True))
+    model = model.to(dev)
     history = load_data()
     s, p, v = zip(*history)
-    s = torch.from_numpy(model.preprocess_input(s)).to('cuda')                     # uint8 [n,72]
-    p = torch.tensor(np.array(p), dtype=torch.float32, device='cuda')              # policy targets
-    v = torch.tensor(np.array(v), dtype=torch.float32, device='cuda')              # value targets
+    s = torch.from_numpy(model.preprocess_input(s)).to(dev)                        # uint8 [n,72]
+    p = torch.tensor(np.array(p), dtype=torch.float32, device=dev)                 # policy targets
+    v = torch.tensor(np.array(v), dtype=torch.float32, device=dev)                 # value targets
     n = s.shape[0]
     trainer = GNNTrainer(model, max_batch=BATCH_SIZE)
     for epoch in range(NUM_EPOCH):
         lr = LEARNING_RATE * lr_lambda(epoch)                                      # LambdaLR, stepped once per epoch (:98)
-        perm = torch.randperm(n, device='cuda')                                    # DataLoader(shuffle=True), last batch kept
+        perm = torch.randperm(n, device=dev)                                    # DataLoader(shuffle=True), last batch kept
         if world > 1:
             if dist.get_backend() == 'nccl':
                 dist.broadcast(perm, src=0)
             else:                                                                  # gloo (tests): host tensors only
                 perm_h = perm.cpu()
                 dist.broadcast(perm_h, src=0)
-                perm = perm_h.to('cuda')
+                perm = perm_h.to(dev)
         if world == 1:
             epoch_policy_loss, epoch_value_loss = trainer.run_epoch(s, p, v, perm, lr=lr)
         else:
-            epoch_policy_loss = torch.zeros((), device='cuda')
-            epoch_value_loss = torch.zeros((), device='cuda')
+            epoch_policy_loss = torch.zeros((), device=dev)
+            epoch_value_loss = torch.zeros((), device=dev)
             for i in range(0, n, BATCH_SIZE):
                 idx = perm[i:i + BATCH_SIZE][rank::world]
                 pl, vl = trainer.step(s[idx], p[idx], v[idx], lr=lr)

@@ -1056,37 +1056,23 @@ def test_self_play_generations_differ_unless_seeded(dev, tmp_path, monkeypatch):
     assert sp.self_play(model, games=6) == c
 
 
-_SHARD_WORKER = r"""
-import os, sys, pickle
-sys.path.insert(0, os.environ["AQG_REPO"])
-import numpy as np, torch, torch.distributed as dist
-from alphaquoridorgnn_amd import self_play as sp, pv_mcts, train_cycle as tc, train_network as tn, evaluate_network as en
-from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
-from oracle import gnn as og
-rank = int(os.environ["RANK"])
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["AQG_PORT"], rank=rank, world_size=2)
-os.chdir(os.environ["AQG_CWD"])
-pv_mcts.PV_EVALUATE_COUNT = 8
-if os.environ["AQG_MODE"] == "selfplay":
-    m = GNNNetwork(); m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in og.init_params(2).items()}); m = m.to("cuda").eval()
-    sp.self_play(m, games=7, seed=500)                       # rank 0: 4 games, rank 1: 3 games
-else:
-    sp.SP_GAME_COUNT = 6; tn.NUM_EPOCH = 2; en.EN_GAME_COUNT = 4
-    out = tc.train_cycle(num_cycles=2)
-    sd = torch.load(os.path.join("models", "GNN", "9x9", "latest.pth"), map_location="cpu", weights_only=True)
-    with open(f"cycle.{rank}.pkl", "wb") as f:
-        pickle.dump((out, {k: v.numpy() for k, v in sd.items()}), f)
-dist.barrier()
-dist.destroy_process_group()
-"""
-
-
-def _run_two_ranks(tmp_path, mode, **extra_env):
+def _torchrun_two_ranks(tmp_path, module, *args, **extra_env):
+    """Two ranks through the package's own multi-rank entry, exactly as INTEGRATION.md launches it (torch.distributed.run with one
+    process per rank; here backend gloo and both ranks on this one GPU -- RCCL needs a GPU per rank, the host code path is the
+    same): `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P -m <module> ...`."""
     import subprocess
-    (tmp_path / "worker.py").write_text(_SHARD_WORKER)
-    env = dict(os.environ, AQG_REPO=REPO, AQG_PORT=str(29900 + os.getpid() % 90), AQG_CWD=str(tmp_path), AQG_MODE=mode, **extra_env)
-    procs = [subprocess.Popen([sys.executable, str(tmp_path / "worker.py")], env=dict(env, RANK=str(r))) for r in range(2)]
-    assert all(p.wait(timeout=900) == 0 for p in procs)
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""), AQG_DIST_BACKEND="gloo", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90), "-m", module] + [str(a) for a in args]
+    res = subprocess.run(cmd, env=env, cwd=str(tmp_path), timeout=900, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+
+
+def _write_best(tmp_path, seed):
+    from oracle import gnn as og
+    d = tmp_path / "models" / "GNN" / "9x9"
+    d.mkdir(parents=True, exist_ok=True)
+    torch.save({k: torch.from_numpy(v.copy()) for k, v in og.init_params(seed).items()}, str(d / "best.pth"))
 
 
 def test_sharded_self_play_two_ranks_equals_standalone_engines(dev, tmp_path):
@@ -1096,7 +1082,8 @@ def test_sharded_self_play_two_ranks_equals_standalone_engines(dev, tmp_path):
     import pickle
     from alphaquoridorgnn_amd.engine import MultiSetSelfPlay
     from alphaquoridorgnn_amd import self_play as sp
-    _run_two_ranks(tmp_path, "selfplay")
+    _write_best(tmp_path, 2)
+    _torchrun_two_ranks(tmp_path, "alphaquoridorgnn_amd.self_play", "--games", 7, "--sims", 8, "--seed", 500)   # rank 0: 4 games, rank 1: 3
     files = sorted((tmp_path / "data").glob("*.history"))
     assert len(files) == 1
     with open(files[0], "rb") as f:
@@ -1116,15 +1103,16 @@ def test_train_cycle_two_ranks(dev, tmp_path, data_parallel):
     reads it early) -- by rank 0 alone (the default: the batch-128 step is latency-bound, sharding it cannot speed it up) or
     data-parallel (AQG_TRAIN_DATA_PARALLEL=1) --, evaluation by rank 0 with the decision broadcast.  Both ranks must agree on
     the promotions and hold identical weights; every cycle leaves one history file."""
-    import pickle
-    _run_two_ranks(tmp_path, "cycle", AQG_TRAIN_DATA_PARALLEL=data_parallel)
+    import json
+    _torchrun_two_ranks(tmp_path, "alphaquoridorgnn_amd.train_cycle", "--cycles", 2, "--games", 6, "--sims", 8, "--epochs", 2,
+                        "--eval-games", 4, "--result-dir", ".", AQG_TRAIN_DATA_PARALLEL=data_parallel)
     outs = []
     for r in range(2):
-        with open(tmp_path / f"cycle.{r}.pkl", "rb") as f:
-            outs.append(pickle.load(f))
-    assert outs[0][0] == outs[1][0] and len(outs[0][0]) == 2
-    for k in outs[0][1]:
-        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+        with open(tmp_path / f"train_cycle.rank{r}.json") as f:
+            outs.append(json.load(f))
+    assert [o["rank"] for o in outs] == [0, 1] and all(o["world"] == 2 for o in outs)
+    assert outs[0]["promoted"] == outs[1]["promoted"] and len(outs[0]["promoted"]) == 2
+    assert outs[0]["latest_sha256"] == outs[1]["latest_sha256"]
     # one history file per generation, named by the second like the reference's (self_play.py:33-35): two of these tiny
     # generations can share a name
     assert 1 <= len(list((tmp_path / "data").glob("*.history"))) <= 2

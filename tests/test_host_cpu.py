@@ -128,14 +128,16 @@ def test_weight_packing_layout():
         assert np.array_equal(wh[0], hi[nn, kk].view(np.uint16)) and np.array_equal(wh[1], lo[nn, kk].view(np.uint16))
         rec = hi.astype(np.float64) + lo.astype(np.float64)
         assert np.max(np.abs(rec - W)) <= 2.0 ** -22 * np.max(np.abs(W))
-    # layer-1 fragments: k-slots 0..7 = hi(W1[n][0..5]),0,0   8..15 = lo(...),0,0   16..31 = 0
+    # layer-1 fragments (aggregate-first layer 1: A operand, rows = output features): k-slots 0..7 and 8..15 = hi(c W1[n][0..5]),0,0
+    # 16..23 = lo(c W1[n][0..5]),0,0   24..31 = 0
     w1 = out[WH1:WH1 + 4 * 2 * 64 * 4].view(np.uint16).reshape(4, 2, 4, 16, 8)                        # [wave][ntile][q][c][8 halves]
-    W = p["gcn_layers.0.lin.weight"].astype(np.float32)                                               # [128, 6]
+    W = (p["gcn_layers.0.lin.weight"].astype(np.float64) * CQ).astype(np.float32)                     # [128, 6]
     hi = W.astype(np.float16)
     lo = (W - hi.astype(np.float32)).astype(np.float16)
     cols = (32 * np.arange(4)[:, None, None] + 16 * np.arange(2)[None, :, None] + np.arange(16)[None, None, :])   # [wave][ntile][c]
-    assert np.array_equal(w1[:, :, 0, :, :6], hi[cols].view(np.uint16)) and np.array_equal(w1[:, :, 1, :, :6], lo[cols].view(np.uint16))
-    assert not w1[:, :, :2, :, 6:].any() and not w1[:, :, 2:].any()
+    assert np.array_equal(w1[:, :, 0, :, :6], hi[cols].view(np.uint16)) and np.array_equal(w1[:, :, 1, :, :6], hi[cols].view(np.uint16))
+    assert np.array_equal(w1[:, :, 2, :, :6], lo[cols].view(np.uint16))
+    assert not w1[:, :, :3, :, 6:].any() and not w1[:, :, 3].any()
     # bias tables of the default trunk: TB[layer][deg - 1][f] = CQ * b[f] * sqrt(deg)   (random-init biases are zero: use a second set)
     p2 = {k: v.copy() for k, v in p.items()}
     rng = np.random.RandomState(3)
@@ -203,6 +205,48 @@ def test_gather_history_world_size_2_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
+
+
+_ENTRY_WORKER = r'''
+import os, sys, time
+import torch, torch.distributed as dist
+from alphaquoridorgnn_amd import distributed as aqd
+rank, world = aqd.init_from_env()                 # torchrun's environment; backend from AQG_DIST_BACKEND (gloo here)
+assert (rank, world) == (int(os.environ["RANK"]), 2) and dist.get_backend() == "gloo"
+assert aqd.init_from_env() == (rank, world)       # idempotent
+# a long single-rank stage: rank 1 must wait on the store (no collective pending), and only leave after rank 0 published
+tag = aqd.next_tag("stage")
+assert tag == "stage/1"
+t0 = time.time()
+if rank == 0:
+    time.sleep(1.5)
+    aqd.release_ranks(tag)
+else:
+    aqd.wait_for_rank0(tag)
+    assert time.time() - t0 > 1.0
+dist.barrier()
+t = torch.tensor([rank + 5], device=aqd.collective_device())
+dist.broadcast(t, src=0)
+assert int(t) == 5 and t.device.type == "cpu"
+aqd.shutdown()
+assert not dist.is_initialized()
+print("entry ok", rank)
+'''
+
+
+def test_multi_rank_entry_under_torchrun_gloo(tmp_path):
+    """The package's multi-rank entry (alphaquoridorgnn_amd/distributed.py, what `-m alphaquoridorgnn_amd.train_cycle` calls first)
+    started the way INTEGRATION.md starts it -- torch.distributed.run, one process per rank, rendezvous on 127.0.0.1 -- with the
+    gloo backend on CPU: ranks / world size from the environment, the store-based wait that keeps idle ranks out of a pending
+    collective while rank 0 works alone, clean shutdown."""
+    script = tmp_path / "entry_worker.py"
+    script.write_text(_ENTRY_WORKER)
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""), AQG_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + (os.getpid() + 7) % 2000), str(script)]
+    res = subprocess.run(cmd, env=env, cwd=str(tmp_path), timeout=300, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "entry ok 0" in res.stdout + res.stderr and "entry ok 1" in res.stdout + res.stderr
 
 
 def test_self_play_sharding_arithmetic():
