@@ -627,14 +627,32 @@ constexpr unsigned int AF_NT_PACK = 0u | (1u << 3) | (1u << 6) | (2u << 9) | (2u
 constexpr int af_kb(int blk) { return (AF_KB_PACK >> (2 * blk)) & 3; }
 constexpr int af_nt(int blk) { return (AF_NT_PACK >> (3 * blk)) & 7; }
 
+// Where a board's inputs are built (developer switches, A/B'd with tools/ab_trunk.py):
+//   AQG_PREFETCH 1: board b + 1's inputs are built under board b's layer 3 into the other buffers (no setup phase per board);
+//                0: at the top of each board.   AQG_AF_AT 0: adjacency fragments together with the G' rows; 1: after layer 1;
+//                2: after the layer-2 linear map, in front of the barrier its early waves wait at anyway.
+#ifndef AQG_PREFETCH
+#define AQG_PREFETCH 0
+#endif
+// timing-only ablations (tools/ab_trunk.py; wrong results by construction, never shipped): AQG_ABL_BAR drops the per-board
+// barriers, AQG_ABL_SETUP builds a workgroup's inputs for its first board only, AQG_ABL_EPI drops the plane stores of the
+// epilogues, AQG_ABL_LDSA the A-fragment reads of the linear maps, AQG_ABL_LIN / AQG_ABL_AGG the MFMAs
+#ifdef AQG_ABL_BAR
+#define AQG_BOARD_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define AQG_BOARD_BARRIER() __syncthreads()
+#endif
+#ifndef AQG_AF_AT
+#define AQG_AF_AT 1
+#endif
 template <int NWV>
 struct alignas(16) TrunkSmemM {
     alignas(16) unsigned char P[2][PPLANE];            // fp16 hi / lo planes of the activation image [node][feature] (scale CQ / D^-1/2)
-    alignas(16) unsigned int AF[2][AF_BLOCKS][64][4];  // B fragments of (A + I) diag(CQ / deg) of a board (fp16, exact); two buffers: board parity
+    alignas(16) unsigned int AF[1 + AQG_PREFETCH][AF_BLOCKS][64][4];   // B fragments of (A + I) diag(CQ / deg) of a board (fp16, exact); [board parity] when prefetching
     // layer-1 input, aggregated FIRST: G'[n][f] = sum over the closed neighbourhood k of n of X0[k][f] / sqrt(deg k), as fp16
     // hi[0..7] | lo[8..15] per node (6 features used, slots 6, 7 stay zero); two buffers: board parity (the next board's rows are
     // written while this board's layers 2, 3 run)
-    alignas(16) unsigned short G16[2][81][16];
+    alignas(16) unsigned short G16[1 + AQG_PREFETCH][81][16];
     alignas(16) float Y[NWV][96];                      // per-wave scratch of the setup: X0[k][f] / sqrt(deg k) of the wave's feature
     alignas(16) unsigned short degv[NWV][NWV == 4 ? 3 : 2][32];   // per wave and block slot: fp16 CQ / deg of the 32 nodes of a k block
 };
@@ -693,9 +711,13 @@ __device__ __forceinline__ void split_fence(u32x4& a, u32x4& b, u32x4& c) {
 // fp16 planes of four consecutive features of one node: hi (11 bits) + lo (next 11 bits) = 22 mantissa bits
 template <int NWV>
 __device__ __forceinline__ void store_split4(TrunkSmemM<NWV>& sm, int off, const f32x4 v) {
+#ifdef AQG_ABL_EPI
+    asm volatile("" :: "v"(v), "v"(off));
+#else
     const unsigned int h01 = cvt_pk_f16(v[0], v[1]), h23 = cvt_pk_f16(v[2], v[3]);
     *reinterpret_cast<u32x2*>(&sm.P[0][off]) = (u32x2){h01, h23};
     *reinterpret_cast<u32x2*>(&sm.P[1][off]) = (u32x2){lo_pair(h01, v[0], v[1]), lo_pair(h23, v[2], v[3])};
+#endif
 }
 
 template <int JT>
@@ -741,17 +763,25 @@ __device__ __forceinline__ void linear_split(const TrunkSmemM<8 / JT>& sm, const
     for (int step = 0; step < 24; ++step) {
         const int m = step >> 2, kb = step & 3;
         if (step < 23) {
+#ifdef AQG_ABL_LDSA
+            nxt[0] = cur[1]; nxt[1] = cur[0];
+#else
             const int o = frag_off(step + 1);
             nxt[0] = *reinterpret_cast<const u32x4*>(&sm.P[0][o]);
             nxt[1] = *reinterpret_cast<const u32x4*>(&sm.P[1][o]);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             f32x4 a = kb == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[j];
+#ifdef AQG_ABL_LIN     // timing-only ablation (tools/ab_trunk.py): the linear map's MFMAs removed, its LDS reads and splits kept alive
+            asm volatile("" : "+v"(a) : "v"(cur[0]), "v"(cur[1]), "v"(Bf[0][j][kb]), "v"(Bf[1][j][kb]));
+#else
             a = mfma_f16(cur[1], Bf[0][j][kb], a);
             a = mfma_f16(cur[0], Bf[1][j][kb], a);
             a = mfma_f16(cur[0], Bf[0][j][kb], a);
+#endif
             acc[j] = a;
             if (m > 0 && kb < 3) split_tile_piece(done[j], m - 1, kb, zh[j], zl[j]);
         }
@@ -830,8 +860,12 @@ __device__ __forceinline__ void aggregate_store(TrunkSmemM<8 / JT>& sm, const un
         if (blk + AHEAD < AF_BLOCKS) af[blk + AHEAD] = *reinterpret_cast<const u32x4*>(&AF[blk + AHEAD][lane][0]);
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
+#ifdef AQG_ABL_AGG     // timing-only ablation: the aggregation's MFMAs removed
+            asm volatile("" : "+v"(out[nt][j]) : "v"(zl[j][kb]), "v"(zh[j][kb]), "v"(af[blk]));
+#else
             out[nt][j] = mfma_f16(zl[j][kb], af[blk], out[nt][j]);
             out[nt][j] = mfma_f16(zh[j][kb], af[blk], out[nt][j]);
+#endif
         }
         // tile nt - 1 was finished by the previous block(s): its epilogue goes out under this tile's MFMAs
         if (nt > 0 && (blk + 1 == AF_BLOCKS || af_nt(blk + 1) != nt)) epilogue(nt - 1);
@@ -1025,16 +1059,6 @@ __device__ __forceinline__ void fused_heads_512(FusedHeadsScratch& sc, __amdgpu_
     }
 }
 
-// Where a board's inputs are built (developer switches, A/B'd with tools/ab_trunk.py):
-//   AQG_PREFETCH 1: board b + 1's inputs are built under board b's layer 3 into the other buffers (no setup phase per board);
-//                0: at the top of each board.   AQG_AF_AT 0: adjacency fragments together with the G' rows; 1: after layer 1;
-//                2: after the layer-2 linear map, in front of the barrier its early waves wait at anyway.
-#ifndef AQG_PREFETCH
-#define AQG_PREFETCH 0
-#endif
-#ifndef AQG_AF_AT
-#define AQG_AF_AT 1
-#endif
 // (hipcc's second launch-bound argument is waves per SIMD: workgroups per CU x waves per workgroup / 4 SIMDs)
 template <int JT, int WGS_PER_CU, bool FUSE = false>
 __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trunk_boards_mm_kernel(const void* __restrict__ states, int fmt, int B,
@@ -1108,7 +1132,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     // their first reader sits behind the first board's setup barrier.
     {
         const int t0 = (int)threadIdx.x;
-        for (int i = t0; i < 2 * 81 * 2; i += 64 * NWV)
+        for (int i = t0; i < (1 + AQG_PREFETCH) * 81 * 2; i += 64 * NWV)
             *reinterpret_cast<unsigned int*>(&sm.G16[0][0][0] + 16 * (i >> 1) + 6 + 8 * (i & 1)) = 0u;
     }
     u32x4 Bf[2][JT][4];
@@ -1306,10 +1330,14 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         u32x4 zh[JT][3], zl[JT][3];
         request_bias<JT>(out, rs, 0, toff, wave);                            // lands under the input build + barrier
         AQG_STAMP_AT(6)
+#ifdef AQG_ABL_SETUP
+        if (first) build_inputs(par, hw, vw, hd, 3);
+#else
         if (!AQG_PREFETCH || first) build_inputs(par, hw, vw, hd, AQG_AF_AT == 0 ? 3 : 1);
+#endif
         int bn = b + gridDim.x;
         while (bn < B && active && !active[bn]) bn += gridDim.x;
-        __syncthreads();                     // this board's G' rows and adjacency fragments are complete; the previous board is done
+        AQG_BOARD_BARRIER();                     // this board's G' rows and adjacency fragments are complete; the previous board is done
         AQG_STAMP_AT(0)
         phase_prio(1);
         // ---- layer 1: one MFMA per node tile on top of the bias rows, relu, planes
@@ -1319,9 +1347,11 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights: land under the barrier
         __builtin_amdgcn_sched_barrier(0);
         phase_prio(2);
+#ifndef AQG_ABL_SETUP
         if (AQG_AF_AT == 1) build_inputs(par, hw, vw, hd, 2);
+#endif
         AQG_STAMP_AT(9)
-        __syncthreads();
+        AQG_BOARD_BARRIER();
         AQG_STAMP_AT(1)
         // ---- layer 2
         phase_prio(3);
@@ -1338,12 +1368,12 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         if (bn < B) fetch_record(bn, nrec0, nrec1);                         // the next board's record rides behind it
         __builtin_amdgcn_sched_barrier(0);
         AQG_STAMP_AT(12)
-        __syncthreads();                                                    // every wave is done reading the planes
+        AQG_BOARD_BARRIER();                                                    // every wave is done reading the planes
         AQG_STAMP_AT(13)
         phase_prio(4);
         aggregate_store<JT, false>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, 0);
         AQG_STAMP_AT(14)
-        __syncthreads();
+        AQG_BOARD_BARRIER();
         AQG_STAMP_AT(3)
         // ---- layer 3 + mean pool
         phase_prio(5);
@@ -1363,9 +1393,9 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         if constexpr (FUSE) {
             // the board's heads, right here: the plane image is dead once every wave is past its layer-3 linear map (the barrier)
             FusedHeadsScratch& hs = *reinterpret_cast<FusedHeadsScratch*>(&sm.P[0][0]);
-            __syncthreads();
+            AQG_BOARD_BARRIER();
             aggregate_store<JT, true>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, b * (HID * 4), hs.g);
-            __syncthreads();
+            AQG_BOARD_BARRIER();
             const int tid = 64 * wave + lane;
             fused_heads_512(hs, rs, pk, A, tid, logits ? logits + (size_t)b * A : nullptr, policy ? policy + (size_t)b * A : nullptr,
                             value_pre ? value_pre + b : nullptr, value ? value + b : nullptr);
@@ -1375,9 +1405,11 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         }
         rec0 = nrec0; rec1 = nrec1;
         if (AQG_PREFETCH) par ^= 1;
-        else if (bn < B) __syncthreads();     // single buffers: every wave is done with this board's G' rows / fragments / planes
+        else if (AQG_AF_AT == 0 && bn < B) AQG_BOARD_BARRIER();     // (fragments built in front of the top barrier: layer 3 still reads them)
         first = false;
-        // (no barrier here: the next board's first writes -- its planes, in layer 1 -- sit behind the barrier at the top of the loop)
+        // (No barrier at the end of a board: what the next board writes in front of its top barrier -- the G' rows, wave-private
+        //  scratch -- was last read in layer 1 of this board, three barriers back; its planes and adjacency fragments are written
+        //  behind that barrier, which no wave passes before every wave has finished this board's layer 3.)
         AQG_STAMP_AT(5)
 #ifdef AQG_STAMP
         ++st_n;

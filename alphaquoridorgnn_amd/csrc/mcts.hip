@@ -96,9 +96,15 @@ struct alignas(32) NodeRec {
     int32_t n;         // visit count
     uint32_t kids;     // first child (24 bits) | child count << 24 ; 0 = unexpanded
     uint32_t action;   // action that led to this node (0xFF for the root)
-    uint32_t pad[2];
+    float q;           // f32(-w / n) as PUCT adds it (pv_mcts.py:74), 0 while n == 0: maintained by every writer of (w, n), so the
+                       // descent reads it with the record instead of doing a float64 division per tree level on its critical path
+    uint32_t pad;
 };
 static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
+
+// The exploitation term exactly as the reference forms it: python float division of the float64 sums, rounded to float32 where it
+// meets the float32 exploration term (pv_mcts.py:74 under NumPy-2 promotion; pinned by the reference traces).
+__device__ __forceinline__ float q_of(double w, int n) { return n ? (float)(-w / (double)n) : 0.0f; }
 
 __device__ __forceinline__ NodeRec* game_nodes(const aqg_engine& e, int g) {
     return reinterpret_cast<NodeRec*>(e.node_rec) + (size_t)g * e.node_cap;
@@ -113,6 +119,7 @@ __device__ __forceinline__ void backup_path(NodeRec* __restrict__ nodes, const i
         NodeRec& r = nodes[path[d]];
         r.w += ((depth - d) & 1) ? -leaf_value : leaf_value;
         r.n += 1;
+        r.q = q_of(r.w, r.n);
     }
 }
 
@@ -167,7 +174,7 @@ __global__ void engine_begin_move_kernel(aqg_engine e) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= e.num_games || !e.game_active[g]) return;
     NodeRec root;
-    root.w = 0.0; root.p = 0.f; root.n = 0; root.kids = 0; root.action = 0xFF; root.pad[0] = 0; root.pad[1] = 0;
+    root.w = 0.0; root.p = 0.f; root.n = 0; root.kids = 0; root.action = 0xFF; root.q = 0.f; root.pad = 0;
     game_nodes(e, g)[0] = root;
     e.node_count[g] = 1;
     const int k = e.slot_game[g];                  // the game this slot is playing
@@ -257,6 +264,7 @@ __device__ __forceinline__ void game_select(const aqg_engine& e, int g, int lane
             NodeRec& r = nodes[mynode];
             r.w += ((depth - lane) & 1) ? -value : value;
             r.n += 1;
+            r.q = q_of(r.w, r.n);
         }
         if (lane == 0) {
             e.stat_terminal_sims[g] += 1;
@@ -264,6 +272,7 @@ __device__ __forceinline__ void game_select(const aqg_engine& e, int g, int lane
                 NodeRec& r = nodes[path[d]];
                 r.w += ((depth - d) & 1) ? -value : value;
                 r.n += 1;
+                r.q = q_of(r.w, r.n);
             }
         }
     } else {
@@ -372,7 +381,7 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
             const int i = lane + 64 * r;
             if (i < cnt) {
                 NodeRec c;
-                c.w = 0.0; c.p = pl[r]; c.n = 0; c.kids = 0; c.action = oa[r]; c.pad[0] = 0; c.pad[1] = 0;
+                c.w = 0.0; c.p = pl[r]; c.n = 0; c.kids = 0; c.action = oa[r]; c.q = 0.f; c.pad = 0;
                 nodes[first + i] = c;
             }
         }
@@ -389,11 +398,13 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
             NodeRec& r = nodes[pnode];
             r.w += ((depth - lane) & 1) ? -v : v;
             r.n += 1;
+            r.q = q_of(r.w, r.n);
         }
         for (int d = lane + 64; d <= depth; d += 64) {
             NodeRec& r = nodes[path[d]];
             r.w += ((depth - d) & 1) ? -v : v;
             r.n += 1;
+            r.q = q_of(r.w, r.n);
         }
     }
     if (lane == 0) e.stat_leaf_evals[g] += 1;   // per-game slot: a shared counter would serialise 2048 atomics per step
@@ -507,7 +518,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
                 const int i = lane + 64 * r;
                 if (i < cnt_new) {
                     NodeRec c;
-                    c.w = 0.0; c.p = pl[r]; c.n = 0; c.kids = 0; c.action = oa[r]; c.pad[0] = 0; c.pad[1] = 0;
+                    c.w = 0.0; c.p = pl[r]; c.n = 0; c.kids = 0; c.action = oa[r]; c.q = 0.f; c.pad = 0;
                     nodes[first_new + i] = c;
                 }
             }
@@ -522,17 +533,20 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     const double v_old = (double)value;                              // value.item() -> python float
     // lane d <= depth_old holds the old path node at depth d: its record after the backup (pv_mcts.py:60-66), store pending
     double bw = 0.0; int bn = 0;
+    float bq = 0.f;                   // ... and its exploitation term after the backup: ONE float64 division per step, off the
+                                      // descent's per-level chain (the levels below the root read it by v_readlane)
     const bool fast_old = flag == 1 && depth_old <= fast_depth && depth_old < 63;
     if (flag == 1 && fast_old) {
         if (lane <= depth_old) {
             const NodeRec& r = nodes[pnode];
             bw = r.w + (((depth_old - lane) & 1) ? -v_old : v_old);
             bn = r.n + 1;
+            bq = q_of(bw, bn);
         }
     }
     bool pending = fast_old;          // the old path's updated (w, n) are in registers, not in memory
     auto flush_old = [&]() {
-        if (pending && lane <= depth_old) { NodeRec& r = nodes[pnode]; r.w = bw; r.n = bn; }
+        if (pending && lane <= depth_old) { NodeRec& r = nodes[pnode]; r.w = bw; r.n = bn; r.q = bq; }
         pending = false;
     };
     if (flag == 1 && !fast_old) {     // deep old path: plain read-modify-write through memory, then everything below reads memory
@@ -540,11 +554,13 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
             NodeRec& r = nodes[pnode];
             r.w += ((depth_old - lane) & 1) ? -v_old : v_old;
             r.n += 1;
+            r.q = q_of(r.w, r.n);
         }
         for (int d = lane + 64; d <= depth_old; d += 64) {
             NodeRec& r = nodes[path[d]];
             r.w += ((depth_old - d) & 1) ? -v_old : v_old;
             r.n += 1;
+            r.q = q_of(r.w, r.n);
         }
     }
     if (!do_select) { flush_old(); return; }
@@ -580,9 +596,9 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int i = lane + 64 * r;
-            if (built_now) { rec[r].w = 0.0; rec[r].p = pl[r]; rec[r].n = 0; rec[r].kids = 0; rec[r].action = oa[r]; }
+            if (built_now) { rec[r].w = 0.0; rec[r].p = pl[r]; rec[r].n = 0; rec[r].kids = 0; rec[r].action = oa[r]; rec[r].q = 0.f; }
             else if (i < cnt) rec[r] = nodes[first + i];
-            else { rec[r].w = 0.0; rec[r].p = 0.f; rec[r].n = 0; rec[r].kids = 0; rec[r].action = 0; }
+            else { rec[r].w = 0.0; rec[r].p = 0.f; rec[r].n = 0; rec[r].kids = 0; rec[r].action = 0; rec[r].q = 0.f; }
         }
     };
     if (regs && onpath && depth_old == 0) fetch_children(kids, true);
@@ -598,6 +614,10 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
         // the old path's child of this node: backup delta and (if it is the old leaf) its new child range, in registers
         const bool patch = regs && onpath && depth < depth_old;
         const int pchild = patch ? __builtin_amdgcn_readlane(pnode, (depth + 1) & 63) : -1;
+        // its exploitation term after the pending backup: lane depth + 1 computed it from that node's own record (one division per
+        // step, started before the descent); at the root it is formed here from the round-1 copy, so that level 0 does not wait
+        // for the second load round
+        const float pq = (patch && depth > 0) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bq), (depth + 1) & 63)) : 0.f;
         int t = 0;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -606,6 +626,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
                 if (first + i == pchild) {
                     rec[r].w += ((depth_old - (depth + 1)) & 1) ? -v_old : v_old;
                     rec[r].n += 1;
+                    rec[r].q = depth > 0 ? pq : q_of(rec[r].w, rec[r].n);
                     if (depth + 1 == depth_old) rec[r].kids = kids_new;
                 }
                 t += rec[r].n;
@@ -619,12 +640,9 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
             const int i = lane + 64 * r;
             sc[r] = -INFINITY;
             if (64 * r < cnt) {                                // (wave-uniform: most nodes below the root have < 64 children)
-                const bool visited = __ballot(i < cnt && rec[r].n != 0) != 0;      // wave-uniform: any visited child in this slot?
                 if (i < cnt) {
                     const float u = ((e.c_puct * rec[r].p) * st) / (float)(1 + rec[r].n);
-                    float q = 0.0f;
-                    if (visited) q = rec[r].n ? (float)(-rec[r].w / (double)rec[r].n) : 0.0f;   // (the float64 division is the long pole)
-                    sc[r] = q + u;
+                    sc[r] = rec[r].q + u;                      // q = f32(-w / n) travels with the record (NodeRec::q)
                 }
             }
         }
@@ -681,12 +699,14 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
                 NodeRec& r = nodes[mynode];
                 r.w = nw + (((depth - lane) & 1) ? -tvalue : tvalue);
                 r.n = nn + 1;
+                r.q = q_of(r.w, r.n);
             }
         } else {
             if (lane <= depth && lane < 64) {
                 NodeRec& r = nodes[mynode];
                 r.w += ((depth - lane) & 1) ? -tvalue : tvalue;
                 r.n += 1;
+                r.q = q_of(r.w, r.n);
             }
         }
         if (lane == 0) {
@@ -695,6 +715,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
                 NodeRec& r = nodes[path[d]];
                 r.w += ((depth - d) & 1) ? -tvalue : tvalue;
                 r.n += 1;
+                r.q = q_of(r.w, r.n);
             }
         }
     } else {
