@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQG_LIB_PATH", os.path.join(_HERE, "libaqgnn_hip.so"))  # override: diagnostic builds only
 MAX_LEGAL = 136
 GNN_EXACT_F32 = 1        # AQG_GNN_EXACT_F32 (include/aqgnn.h)
-ABI_VERSION = 6
+ABI_VERSION = 7
 TRAIN_PART_FLOATS = 2 * 128 * 128 + 128 * 6 + 3 * 128    # AQG_TRAIN_PART_FLOATS, per position of the batch
 
 _c = ctypes
@@ -59,6 +59,7 @@ SIGNATURES = {
     "aqg_gcn_packed_floats": (_c.c_size_t, [_c.c_int]),
     "aqg_gcn_pack_weights_host": (_c.c_int, [_c.c_int, _c.POINTER(_vp), _vp]),
     "aqg_gcn_forward_boards": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
+    "aqg_gcn_forward_boards_guarded": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp, _vp]),
     "aqg_gcn_boards_any_workspace_floats": (_c.c_size_t, [_c.c_int, _c.c_int]),
     "aqg_gcn_forward_boards_any": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _c.c_size_t, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "aqg_gcn_forward_graph": (_c.c_int, [_c.c_int, _c.c_int, _vp, _c.c_int, _vp, _vp, _vp, _vp, _c.c_int, _vp, _vp,

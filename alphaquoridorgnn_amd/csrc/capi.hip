@@ -31,11 +31,11 @@ int launch_state_next(int N, const uint8_t* in, const int32_t* actions, int B, u
 int launch_state_status(int N, const uint8_t* in, int B, int draw, uint8_t* flags, hipStream_t st);
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
-                              int flags, hipStream_t st);
+                              int flags, int32_t* saturated, hipStream_t st);
 size_t boards_any_workspace_floats(int N, int B);
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
-                                  float* value, const uint8_t* active, int flags, hipStream_t st);
+                                  float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st);
 int launch_gcn_forward_graph(int F, int A, const float* x, int num_nodes, const int32_t* csr_ptr, const int32_t* csr_src,
                              const float* csr_w, const int32_t* graph_ptr, int num_graphs, const float* packed,
                              float* work0, float* work1, float* pooled, float* logits, float* policy, float* value_pre,
@@ -118,7 +118,16 @@ int aqg_gcn_forward_boards(int board_size, const void* states, int state_fmt, in
     if (B < 0 || (B > 0 && (!states || !packed))) return fail("aqg_gcn_forward_boards: bad arguments");
     if (state_fmt != 0 && state_fmt != 1) return fail("aqg_gcn_forward_boards: state_fmt must be 0 or 1");
     return launch_gcn_forward_boards(board_size, states, state_fmt, B, packed, pooled, logits, policy, value_pre, value, nullptr,
-                                     flags, (hipStream_t)stream);
+                                     flags, nullptr, (hipStream_t)stream);
+}
+
+int aqg_gcn_forward_boards_guarded(int board_size, const void* states, int state_fmt, int B, const float* packed, float* pooled,
+                                   float* logits, float* policy, float* value_pre, float* value, int flags, int32_t* saturated,
+                                   void* stream) {
+    if (B < 0 || (B > 0 && (!states || !packed))) return fail("aqg_gcn_forward_boards_guarded: bad arguments");
+    if (state_fmt != 0 && state_fmt != 1) return fail("aqg_gcn_forward_boards_guarded: state_fmt must be 0 or 1");
+    return launch_gcn_forward_boards(board_size, states, state_fmt, B, packed, pooled, logits, policy, value_pre, value, nullptr,
+                                     flags, saturated, (hipStream_t)stream);
 }
 
 size_t aqg_gcn_boards_any_workspace_floats(int board_size, int B) { return B > 0 ? boards_any_workspace_floats(board_size, B) : 0; }
@@ -129,7 +138,7 @@ int aqg_gcn_forward_boards_any(int board_size, const void* states, int state_fmt
     if (B < 0 || (B > 0 && (!states || !packed))) return fail("aqg_gcn_forward_boards_any: bad arguments");
     if (state_fmt != 0 && state_fmt != 1) return fail("aqg_gcn_forward_boards_any: state_fmt must be 0 or 1");
     return launch_gcn_forward_boards_any(board_size, states, state_fmt, B, packed, workspace, workspace_floats, pooled, logits, policy,
-                                         value_pre, value, nullptr, flags, (hipStream_t)stream);
+                                         value_pre, value, nullptr, flags, nullptr, (hipStream_t)stream);
 }
 
 int aqg_gcn_forward_graph(int num_features, int num_actions, const float* x, int num_nodes, const int32_t* csr_ptr,

@@ -707,6 +707,35 @@ __device__ __forceinline__ void split_fence(u32x4& a, u32x4& b, u32x4& c) {
 // this kernel did its relu in asm and was wrong by different amounts in each of its three forms, depending on what the scheduler
 // happened to put between the last MFMA and the asm.  Every first reader of an accumulator is compiler-visible code now.)
 
+// Runtime fp16-range guard.  The split kernels are fp32-equivalent only while every value they store as fp16 pairs stays inside
+// fp16 range: the post-ReLU activations (clamped at 65504 instead of overflowing) and the linear maps' outputs (converted as they
+// are split).  Every epilogue tracks the PRE-clamp bit patterns of what it stores (track_range): that sees an activation beyond
+// the range, and it sees a linear-map output beyond it as well -- such a z becomes +-inf in its hi half (and -+inf in its lo
+// half), every banded adjacency block multiplies it by exact zeros, and 0 x inf = NaN lands in the accumulators of its node
+// tile (layer 3's lands in the pooled row, which the heads kernel checks).  A launch that met such a value ORs 1 into the caller's `saturated` word: the host then serves the
+// weight set with the exact f32-input kernels (pv_network_gnn / engine).  The reference's fp32 has no such cliff
+// (pv_network_gnn.py:53-64).  tests/test_gpu_parity.py::test_gnn_runtime_saturation_signal drives all three cases.
+constexpr int F16_MAX_BITS = 0x477FE000;      // 65504.0f
+// As SIGNED integers the patterns of the positive floats order like the floats and lie above every negative float: the signed
+// maximum exceeds 65504's pattern exactly when a value (or +inf, or a NaN with a clear sign bit) does.  As UNSIGNED integers -inf
+// and the NaNs with the sign bit set lie above everything else: 0 x (-inf) in an adjacency block gives such a NaN on this
+// hardware, and relu maps it to 0 without a trace.  Two v_max3 per four values each.
+__device__ __forceinline__ void track_range(const f32x4 v, int& imax, unsigned int& umax) {
+    const int i0 = __builtin_bit_cast(int, v[0]), i1 = __builtin_bit_cast(int, v[1]), i2 = __builtin_bit_cast(int, v[2]), i3 = __builtin_bit_cast(int, v[3]);
+    imax = max(max(i0, i1), imax);
+    imax = max(max(i2, i3), imax);
+    umax = max(max((unsigned int)i0, (unsigned int)i1), umax);
+    umax = max(max((unsigned int)i2, (unsigned int)i3), umax);
+}
+__device__ __forceinline__ bool out_of_range(int imax, unsigned int umax) { return imax > F16_MAX_BITS || umax >= 0xFF800000u; }
+__device__ __forceinline__ void report_saturation(bool lane_saw_it, int32_t* __restrict__ saturated) {
+    if (saturated && __builtin_amdgcn_ballot_w64(lane_saw_it) != 0) {            // wave-uniform, practically never taken
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        if (l == 0) atomicOr(saturated, 1);
+    }
+}
+
 // A wave owns JT 16-column feature tiles: JT = 2 -> 4 waves per board, JT = 1 -> 8 waves per board.
 // fp16 planes of four consecutive features of one node: hi (11 bits) + lo (next 11 bits) = 22 mantissa bits
 template <int NWV>
@@ -819,8 +848,11 @@ __device__ __forceinline__ void request_bias(f32x4 (&out)[6][JT], __amdgpu_buffe
 // (No plane byte is read here: the caller has passed the barrier behind the linear map, the stores are free to go.)
 template <int JT, bool LAST>
 __device__ __forceinline__ void aggregate_store(TrunkSmemM<8 / JT>& sm, const unsigned int (&AF)[AF_BLOCKS][64][4], u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], f32x4 (&out)[6][JT], int wave, int lane,
-                                                const int (&toff)[3], __amdgpu_buffer_rsrc_t pooled_rs, int pooled_soff, float* pooled_lds = nullptr) {
-    constexpr int AHEAD = 3;                                   // adjacency fragments in flight (4 registers each)
+                                                const int (&toff)[3], __amdgpu_buffer_rsrc_t pooled_rs, int pooled_soff, int32_t* __restrict__ saturated,
+                                                float* pooled_lds = nullptr) {
+    constexpr int AHEAD = 3;
+    int imax = 0;                                              // fp16-range guard: largest pre-clamp bit pattern, signed ...
+    unsigned int umax = 0u;                                    // ... and unsigned (see track_range)                                   // adjacency fragments in flight (4 registers each)
     const int c = lane & 15, q = lane >> 4;
     const int col0 = 16 * JT * wave + 4 * q;
     u32x4 af[AF_BLOCKS];
@@ -840,13 +872,16 @@ __device__ __forceinline__ void aggregate_store(TrunkSmemM<8 / JT>& sm, const un
         for (int j = 0; j < JT; ++j) {
             f32x4 v = out[nt][j];
             if (LAST) {
+                if (live) track_range(v, imax, umax);          // (only inf / NaN matter here: the pooled row is f32, the heads check its range)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
                 if (live) sum[j] += v * dn;
             } else {
                 // relu, saturating at the largest finite fp16: an overflowing activation stays a (wrong) finite number
-                // instead of becoming inf - inf = NaN that the next relu would silently turn into 0.  The host checks
-                // every weight set against the exact-f32 trunk before it trusts this kernel (pv_network_gnn.packed_weights).
+                // instead of becoming inf - inf = NaN that the next relu would silently turn into 0 -- and is REPORTED (imax):
+                // the host then serves the weight set with the exact-f32 kernels (and checks every set on calibration boards
+                // before it trusts this kernel at all, pv_network_gnn.packed_weights).
+                if (live) track_range(v, imax, umax);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = relu_sat16(v[e]);
                 if (live) store_split4(sm, plane_off(node, (col0 + 16 * j) >> 3) + ((2 * (col0 + 16 * j)) & 15), v);
@@ -871,6 +906,7 @@ __device__ __forceinline__ void aggregate_store(TrunkSmemM<8 / JT>& sm, const un
         if (nt > 0 && (blk + 1 == AF_BLOCKS || af_nt(blk + 1) != nt)) epilogue(nt - 1);
     }
     epilogue(5);
+    report_saturation(LAST ? (imax >= 0x7F800000 || umax >= 0xFF800000u) : out_of_range(imax, umax), saturated);
     if (LAST) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -913,8 +949,10 @@ __device__ __forceinline__ float lane_sel(uint64_t m, float a) {
 // 6 MFMAs per wave and feature tile where the linear-first form needed 6 + 20 (X0 W1, then the 128-wide banded aggregation).
 template <int JT>
 __device__ __forceinline__ void layer1_store(TrunkSmemM<8 / JT>& sm, const unsigned short (&G)[81][16], const u32x4 (&w1f)[JT], f32x4 (&out)[6][JT],
-                                             int wave, int lane) {
+                                             int wave, int lane, int32_t* __restrict__ saturated) {
     const int c = lane & 15, q = lane >> 4;
+    int imax = 0;
+    unsigned int umax = 0u;
     const int col0 = 16 * JT * wave + 4 * q;
     u32x4 gf[6];
 #pragma unroll
@@ -930,11 +968,13 @@ __device__ __forceinline__ void layer1_store(TrunkSmemM<8 / JT>& sm, const unsig
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             f32x4 v = out[nt][j];
+            if (live) track_range(v, imax, umax);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = relu_sat16(v[e]);
             if (live) store_split4(sm, plane_off(node, (col0 + 16 * j) >> 3) + ((2 * (col0 + 16 * j)) & 15), v);
         }
     }
+    report_saturation(out_of_range(imax, umax), saturated);
 }
 
 __device__ __forceinline__ uint32_t bit_of64(uint64_t m, int s) {             // bit s of a wave-uniform 64-bit mask
@@ -1068,7 +1108,8 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
                                                                                         int A = 0, float* __restrict__ logits = nullptr,
                                                                                         float* __restrict__ policy = nullptr,
                                                                                         float* __restrict__ value_pre = nullptr,
-                                                                                        float* __restrict__ value = nullptr) {
+                                                                                        float* __restrict__ value = nullptr,
+                                                                                        int32_t* __restrict__ saturated = nullptr) {
     static_assert(!FUSE || JT == 1, "the fused heads are written for the 512-thread form");
     AQG_TRACE_BEGIN
     constexpr int N = 9, V = 81, S = 8;
@@ -1341,7 +1382,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         AQG_STAMP_AT(0)
         phase_prio(1);
         // ---- layer 1: one MFMA per node tile on top of the bias rows, relu, planes
-        layer1_store<JT>(sm, sm.G16[par], w1f, out, wave, lane);
+        layer1_store<JT>(sm, sm.G16[par], w1f, out, wave, lane, saturated);
         AQG_STAMP_AT(8)
         __builtin_amdgcn_sched_barrier(0);
         load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights: land under the barrier
@@ -1371,7 +1412,7 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         AQG_BOARD_BARRIER();                                                    // every wave is done reading the planes
         AQG_STAMP_AT(13)
         phase_prio(4);
-        aggregate_store<JT, false>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, 0);
+        aggregate_store<JT, false>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, 0, saturated);
         AQG_STAMP_AT(14)
         AQG_BOARD_BARRIER();
         AQG_STAMP_AT(3)
@@ -1394,14 +1435,14 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
             // the board's heads, right here: the plane image is dead once every wave is past its layer-3 linear map (the barrier)
             FusedHeadsScratch& hs = *reinterpret_cast<FusedHeadsScratch*>(&sm.P[0][0]);
             AQG_BOARD_BARRIER();
-            aggregate_store<JT, true>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, b * (HID * 4), hs.g);
+            aggregate_store<JT, true>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, b * (HID * 4), saturated, hs.g);
             AQG_BOARD_BARRIER();
             const int tid = 64 * wave + lane;
             fused_heads_512(hs, rs, pk, A, tid, logits ? logits + (size_t)b * A : nullptr, policy ? policy + (size_t)b * A : nullptr,
                             value_pre ? value_pre + b : nullptr, value ? value + b : nullptr);
         } else {
             phase_prio(6);
-            aggregate_store<JT, true>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, b * (HID * 4));
+            aggregate_store<JT, true>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, b * (HID * 4), saturated);
         }
         rec0 = nrec0; rec1 = nrec1;
         if (AQG_PREFETCH) par ^= 1;
@@ -1578,7 +1619,8 @@ struct alignas(16) HeadsSmem {
 __global__ __launch_bounds__(256, 2) void gcn_heads_mm_kernel(const float* __restrict__ pooled, int B, int A,
                                                               const float* __restrict__ pk, float* __restrict__ logits,
                                                               float* __restrict__ policy, float* __restrict__ value_pre,
-                                                              float* __restrict__ value, const uint8_t* __restrict__ active, int prio) {
+                                                              float* __restrict__ value, const uint8_t* __restrict__ active, int prio,
+                                                              int32_t* __restrict__ saturated) {
     __shared__ HeadsSmem sm;
     AQG_TRACE_BEGIN
     if (prio) __builtin_amdgcn_s_setprio(1);       // a short latency chain: let it out of the trunk workgroups' way quickly (option "heads_prio")
@@ -1608,15 +1650,20 @@ __global__ __launch_bounds__(256, 2) void gcn_heads_mm_kernel(const float* __res
             }
     // B operand of layer 1: 32 pooled features of board (b0 + c), split
     u32x4 ph[4], pl_[4];
+    const bool counted = b0 + c < B && !(active && !active[b0 + c]);  // (fp16-range guard) a masked-out board's pooled row is whatever the buffer held
     {
         const bool ok = b0 + c < B;
         const float* row = pooled + (size_t)(ok ? b0 + c : B - 1) * HID + 8 * q;
+        float xmax = 0.f;                                              // fp16-range guard (see report_saturation)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             f32x4 x0 = *reinterpret_cast<const f32x4*>(row + 32 * kb), x1 = *reinterpret_cast<const f32x4*>(row + 32 * kb + 4);
             if (!ok) { x0 = (f32x4){0.f, 0.f, 0.f, 0.f}; x1 = x0; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xmax = fmaxf(fmaxf(fabsf(x0[e]), fabsf(x1[e])), xmax);
             split8(x0, x1, ph[kb], pl_[kb]);
         }
+        report_saturation(counted && !(xmax <= 65504.0f), saturated);  // (!(<=) also catches a NaN row)
     }
     // ---- phase 1
     u32x4 fh, fl;                                              // waves 0/1: this wave's layer-2 A fragment (kb2 = wave)
@@ -1635,6 +1682,8 @@ __global__ __launch_bounds__(256, 2) void gcn_heads_mm_kernel(const float* __res
         f32x4 h = acc + bias;
 #pragma unroll
         for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
+        // (hidden units 16 ut + 4 q + e of board b0 + c, stored as fp16 pairs for the policy head's second layer: same guard)
+        if (wave < 2) report_saturation(counted && !(fmaxf(fmaxf(h[0], h[1]), fmaxf(h[2], h[3])) <= 65504.0f), saturated);
         if (wave < 2) {
             const unsigned int h01 = cvt_pk_f16(h[0], h[1]), h23 = cvt_pk_f16(h[2], h[3]);
             const f32x4 r = h - f16_pairs_to_f32(h01, h23);
@@ -1823,7 +1872,7 @@ int profile_collect(double* total_ms, long long* launches, long long* boards, in
 
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
-                              int flags, hipStream_t st) {
+                              int flags, int32_t* saturated, hipStream_t st) {
     if (N != 9) return fail("fused board trunk is built for 9x9; use aqg_gcn_forward_graph for other sizes");
     if (B <= 0) return 0;
     if (!pooled) return fail("pooled workspace is required");
@@ -1843,7 +1892,8 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
         // two 4-wave workgroups per CU (a wave owns 32 feature columns): half the LDS operand traffic of the 8-wave form
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16));
+        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),
+                           0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, saturated);
     } else {
         // two 8-wave workgroups per CU (a wave owns 16 feature columns): shortest latency per board AND, with four waves per
         // SIMD to hide each other's vector work, the highest throughput at every launch size (tools/trunk_scan.py)
@@ -1852,10 +1902,11 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
         const bool want_heads = logits || policy || value_pre || value;
         if (want_heads && g_fuse_heads && B <= FUSE_HEADS_MAX && N * N + 2 * (N - 1) * (N - 1) <= APAD) {
             hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2, true>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, 0,
-                               N * N + 2 * (N - 1) * (N - 1), logits, policy, value_pre, value);
+                               N * N + 2 * (N - 1) * (N - 1), logits, policy, value_pre, value, saturated);
             fused = true;
         } else {
-            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16));
+            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),
+                               0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, saturated);
         }
     }
     if (g_profile_trunk == 1) (void)hipEventRecord(prof_event(), st);
@@ -1864,7 +1915,7 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     if (!logits && !policy && !value_pre && !value) return 0;   // trunk only (bench: time the dominant kernel alone)
     if (variant >= 3 && A <= 14 * 16) {
         hipLaunchKernelGGL(gcn_heads_mm_kernel, dim3((B + 15) / 16), dim3(256), 0, st, (const float*)pooled, B, A, packed,
-                           logits, policy, value_pre, value, active, g_heads_prio);
+                           logits, policy, value_pre, value, active, g_heads_prio, saturated);
         return check_launch("gcn_heads_mm_kernel");
     }
     hipLaunchKernelGGL(gcn_heads_kernel, dim3((B + HB - 1) / HB), dim3(256), 0, st, (const float*)pooled, B, A, packed,
@@ -2024,8 +2075,8 @@ size_t boards_any_workspace_floats(int N, int B) { return (size_t)B * N * N * 27
 
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
-                                  float* value, const uint8_t* active, int flags, hipStream_t st) {
-    if (N == 9) return launch_gcn_forward_boards(N, states, fmt, B, packed, pooled, logits, policy, value_pre, value, active, flags, st);
+                                  float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st) {
+    if (N == 9) return launch_gcn_forward_boards(N, states, fmt, B, packed, pooled, logits, policy, value_pre, value, active, flags, saturated, st);
     if (!(N == 3 || N == 5 || N == 7)) return fail("board_size must be 3, 5, 7 or 9");
     if (B <= 0) return 0;
     if (!pooled) return fail("pooled workspace is required");

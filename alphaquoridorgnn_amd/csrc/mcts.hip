@@ -30,11 +30,11 @@ int launch_legal_actions(int N, const void* states, int fmt, int B, uint8_t* mas
                          const uint8_t* active, hipStream_t st);
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
-                              int flags, hipStream_t st);
+                              int flags, int32_t* saturated, hipStream_t st);
 size_t boards_any_workspace_floats(int N, int B);
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
-                                  float* value, const uint8_t* active, int flags, hipStream_t st);
+                                  float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st);
 extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, g_profile_trunk, g_fuse_heads, g_trunk_prio, g_heads_prio;
 void profile_mark(hipStream_t st, long long units);
 int g_use_graph = 1;       // aqg_set_option("use_graph", 0) forces plain launches
@@ -969,7 +969,7 @@ static int enqueue_sims(const aqg_engine& e, hipStream_t st) {
             // 9x9: the fused trunk; smaller boards: plain kernels over e.gnn_workspace
             if (int r = launch_gcn_forward_boards_any(N, e.leaf_state, 1, e.num_games, e.packed_weights, e.gnn_workspace,
                                                       e.gnn_workspace ? boards_any_workspace_floats(N, e.num_games) : 0, e.pooled, nullptr,
-                                                      e.policy, nullptr, e.value, e.leaf_flag, e.gnn_flags, st))
+                                                      e.policy, nullptr, e.value, e.leaf_flag, e.gnn_flags, e.counters + 5, st))
                 return r;
         } else {
             hipLaunchKernelGGL(engine_fake_eval_kernel<N>, grid, block, 0, st, e);

@@ -177,8 +177,19 @@ class BatchedSelfPlay:
     def counters(self):
         c = self.t["counters"].cpu().numpy()
         return dict(active=int(c[0]), finished=int(c[1]), dead_ends=int(c[2]), started=int(c[3]), moves=int(c[4]),
+                    gnn_saturated=int(c[5]),      # the split kernels' fp16-range guard fired during this generation (aqgnn.h counters[5])
                     leaf_evals=int(self.t["stat_leaf_evals"].sum().item()),
                     terminal_sims=int(self.t["stat_terminal_sims"].sum().item()))
+
+    def _fall_back_to_exact_kernels(self):
+        """The range guard fired: this weight set leaves fp16 range on positions of this generation.  Its evaluations so far
+        were finite but not the network's, so the generation is played again from the start on the exact f32-input kernels
+        (the reference's fp32 has no such cliff, pv_network_gnn.py:53-64)."""
+        if self.model is not None and hasattr(self.model, "mark_saturated"):
+            self.model.mark_saturated(self.dev)
+        self._gnn_flags = _lib.GNN_EXACT_F32
+        self.e.gnn_flags = _lib.GNN_EXACT_F32
+        self.reset()
 
     def play_generation(self, uniforms=None, check_every=4):
         """Play the whole quota (== every slot once when quota == num_games: one self_play generation's worth of games
@@ -189,7 +200,12 @@ class BatchedSelfPlay:
             self.move(None if uniforms is None else uniforms[ply])
             ply += 1
             if ply >= limit or ply % check_every == 0:
-                if self.counters()["active"] == 0 or ply >= limit:
+                c = self.counters()
+                if c["gnn_saturated"] and self.e.gnn_flags == 0:
+                    self._fall_back_to_exact_kernels()
+                    ply = 0
+                    continue
+                if c["active"] == 0 or ply >= limit:
                     break
         return self.counters()
 
@@ -270,6 +286,8 @@ class MultiSetSelfPlay:
         if key not in _SET_STREAMS:
             _SET_STREAMS[key] = [torch.cuda.Stream(device=self.dev) for _ in sizes]
         self.streams = _SET_STREAMS[key]
+        if model is not None and kw.get("evaluator", "gnn") == "gnn":
+            model.packed_weights(self.dev)        # pack + calibrate (two forwards and a host sync) on the caller's stream, not inside set 0's
         self.sets = []
         ready = torch.cuda.current_stream(self.dev).record_event()   # e.g. the model's weight upload on the caller's stream
         for i, g in enumerate(sizes):
@@ -331,7 +349,7 @@ class MultiSetSelfPlay:
         return self._live[k]
 
     def counters(self):
-        tot = dict(active=0, finished=0, dead_ends=0, started=0, moves=0, leaf_evals=0, terminal_sims=0)
+        tot = dict(active=0, finished=0, dead_ends=0, started=0, moves=0, gnn_saturated=0, leaf_evals=0, terminal_sims=0)
         for i, eng in self._each():
             c = eng.counters()                    # .cpu() inside synchronises this set's stream only
             self._live[i] = self._live[i] and c["active"] > 0
@@ -346,7 +364,14 @@ class MultiSetSelfPlay:
             self.move()
             ply += 1
             if ply >= limit or ply % check_every == 0:
-                if self.counters()["active"] == 0 or ply >= limit:
+                c = self.counters()
+                if c["gnn_saturated"] and any(e.e.gnn_flags == 0 for e in self.sets):
+                    for _, eng in self._each():          # fp16-range guard: replay the generation on the exact f32 kernels
+                        eng._fall_back_to_exact_kernels()
+                    self._live = [True] * len(self.sets)
+                    ply = 0
+                    continue
+                if c["active"] == 0 or ply >= limit:
                     break
         return self.counters()
 

@@ -77,6 +77,7 @@ class GraphPolicyValueNetwork(nn.Module):
         self._packed = None
         self._packed_key = None
         self._gnn_flags = 0
+        self._sat_words = {}          # device -> int32 [1]: the runtime fp16-range guard's word (aqg_gcn_forward_boards_guarded)
 
     # ---------------------------------------------------------------- weight packing
     def packed_weights(self, device):
@@ -93,6 +94,8 @@ class GraphPolicyValueNetwork(nn.Module):
                        "aqg_gcn_pack_weights_host")
             self._packed = out.to(device)
             self._packed_key = key
+            for w in self._sat_words.values():
+                w.zero_()
             self._gnn_flags = self._calibrate(self._packed, device)
         return self._packed
 
@@ -104,9 +107,25 @@ class GraphPolicyValueNetwork(nn.Module):
 
     def gnn_flags(self, device):
         """Flags every GNN forward of this weight set must carry (0, or _lib.GNN_EXACT_F32 when the fp16-split kernels
-        cannot represent its activations: see _calibrate)."""
+        cannot represent its activations: found on the calibration boards when the set is packed (_calibrate), or at run time
+        by the kernels' range guard (mark_saturated))."""
         self.packed_weights(device)
         return self._gnn_flags
+
+    def saturation_word(self, device):
+        """The int32 device word the split kernels OR 1 into when they meet a value outside fp16 range (include/aqgnn.h,
+        aqg_gcn_forward_boards_guarded); one per device, zero until that happens."""
+        key = str(device)
+        if key not in self._sat_words:
+            self._sat_words[key] = torch.zeros((1,), dtype=torch.int32, device=device)
+        return self._sat_words[key]
+
+    def mark_saturated(self, device=None):
+        """The range guard fired for this weight set (a forward of this module, or an engine evaluating with it): from now on --
+        until the parameters change -- it is served by the exact f32-input kernels, like a set that fails calibration."""
+        self._gnn_flags = _lib.GNN_EXACT_F32
+        for w in self._sat_words.values():
+            w.zero_()
 
     _calib_boards = {}
 
@@ -140,21 +159,28 @@ class GraphPolicyValueNetwork(nn.Module):
         boards = self._calibration_boards(device)
         B, A = boards.shape[0], self.policy_output_size
         res = []
+        word = torch.zeros((1,), dtype=torch.int32, device=device)
         for flags in (0, _lib.GNN_EXACT_F32):
             pooled = torch.empty((B, HIDDEN_DIM), dtype=torch.float32, device=device)
             logits = torch.empty((B, A), dtype=torch.float32, device=device)
             vpre = torch.empty((B,), dtype=torch.float32, device=device)
-            _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(boards), 0, B, _lib.ptr(packed), _lib.ptr(pooled), _lib.ptr(logits),
-                                                  None, _lib.ptr(vpre), None, flags, _lib.stream_ptr(device)), "calibration forward")
+            _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(boards), 0, B, _lib.ptr(packed), _lib.ptr(pooled), _lib.ptr(logits),
+                                                          None, _lib.ptr(vpre), None, flags, _lib.ptr(word), _lib.stream_ptr(device)),
+                       "calibration forward")
             res.append(torch.cat([logits, vpre.unsqueeze(1)], 1).double())
         split, exact = res
         ok = bool(((split - exact).abs() <= 1e-4 + 1e-3 * exact.abs()).all())    # NaN compares False
+        ok = ok and int(word.item()) == 0                                         # the kernels' own range guard, on the same boards
         return 0 if ok else _lib.GNN_EXACT_F32
 
     # ---------------------------------------------------------------- fused board path
-    def forward_states(self, states72, want_logits=False, state_fmt=0):
+    def forward_states(self, states72, want_logits=False, state_fmt=0, check_saturation=True):
         """states72: uint8 [B,72] device tensor (state_fmt=0) -> (policy [B,A] softmaxed, value [B,1] tanh'ed);
-        with want_logits also returns (logits [B,A], value_pre [B])."""
+        with want_logits also returns (logits [B,A], value_pre [B]).
+        check_saturation: after a forward on the fp16-split kernels the range guard's word is read back (one 4-byte copy, a
+        host sync); if a value left fp16 range the weight set is marked (mark_saturated) and the call is repeated on the
+        exact f32-input kernels, so the caller always receives the network's outputs -- the reference's fp32 has no cliff
+        (pv_network_gnn.py:53-64).  False skips the read-back (the engine has its own counter, counters()['gnn_saturated'])."""
         dev = _lib.require_gpu(states72.device)
         lib = _lib.load()
         B = states72.shape[0]
@@ -166,11 +192,17 @@ class GraphPolicyValueNetwork(nn.Module):
         logits = torch.empty((B, A), **f32) if want_logits else None
         vpre = torch.empty((B,), **f32) if want_logits else None
         if self.board_size == 9:
-            _lib.check(lib.aqg_gcn_forward_boards(self.board_size, _lib.ptr(states72), state_fmt, B,
-                                                  _lib.ptr(self.packed_weights(dev)), _lib.ptr(pooled), _lib.ptr(logits),
-                                                  _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value), self.gnn_flags(dev),
-                                                  _lib.stream_ptr(dev)),
-                       "aqg_gcn_forward_boards")
+            word = self.saturation_word(dev)
+            for attempt in range(2):
+                flags = self.gnn_flags(dev)
+                _lib.check(lib.aqg_gcn_forward_boards_guarded(self.board_size, _lib.ptr(states72), state_fmt, B,
+                                                              _lib.ptr(self.packed_weights(dev)), _lib.ptr(pooled), _lib.ptr(logits),
+                                                              _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value), flags,
+                                                              _lib.ptr(word), _lib.stream_ptr(dev)),
+                           "aqg_gcn_forward_boards_guarded")
+                if flags or not check_saturation or B == 0 or int(word.item()) == 0:
+                    break
+                self.mark_saturated(dev)          # outside fp16 range: repeat on the exact kernels, and stay there
         else:   # the reference's smaller boards (constants.py:5-20): plain kernels over a caller-owned workspace
             nws = lib.aqg_gcn_boards_any_workspace_floats(self.board_size, B)
             ws = torch.empty((max(int(nws), 1),), **f32)

@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define AQG_MAX_LEGAL 136 /* >= 5 pawn moves + 128 wall placements */
-#define AQG_ABI_VERSION 6
+#define AQG_ABI_VERSION 7
 
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
@@ -89,7 +89,8 @@ int aqg_state_status(int board_size, const uint8_t* states72, int B, int plies_f
  *   VW2 [H/2]    value_head.2.weight                                vb2 [1] (+3 pad)
  *   WF2, WF3     W2^T / W3^T again in f32 MFMA B-fragment order (exact-f32 trunk variants 0/1)
  *   WH2, WH3     fp16 hi/lo planes of W2^T / W3^T in 16x16x32 MFMA B-fragment order (default trunk)
- *   WH1          fp16 hi/lo of gcn_layers.0.lin.weight folded into one 32-deep k block (default trunk, layer 1)
+ *   WH1          fp16 hi/lo of (15/16) gcn_layers.0.lin.weight as A fragments, rows = output features, the split folded into one
+ *                32-deep k block (default trunk: layer 1 runs aggregate-first, (A_hat X) W1)
  * aqg_gcn_packed_floats() returns the total; aqg_gcn_pack_weights_host() fills a HOST buffer from the 14
  * state_dict tensors given as HOST float32 pointers in the key order of KEYS in INTEGRATION.md. */
 size_t aqg_gcn_packed_floats(int board_size);
@@ -115,6 +116,15 @@ int aqg_gcn_pack_weights_host(int board_size, const float* const* tensors_host, 
 int aqg_gcn_forward_boards(int board_size, const void* states, int state_fmt, int B, const float* packed,
                            float* pooled, float* logits, float* policy, float* value_pre, float* value,
                            int flags, void* stream);
+/* The same call with the runtime fp16-range guard: `saturated` (device int32, may be NULL) is OR-ed with 1 by any fp16-split
+ * kernel of the call that met a value it cannot hold as an fp16 pair -- a linear-map output or a post-ReLU activation beyond
+ * 65504 (the activation is clamped there, never inf / NaN), a pooled feature or head hidden unit beyond it.  The results of such
+ * a call are finite but not the network's: the caller repeats it with AQG_GNN_EXACT_F32 and keeps that flag for the weight set
+ * (GraphPolicyValueNetwork.forward_states / predict do; the engine reports the same event in counters[5]).  The word is never
+ * cleared by the library.  Exact-f32 calls never set it.  Reference behaviour: fp32 throughout, no cliff (pv_network_gnn.py:53-64). */
+int aqg_gcn_forward_boards_guarded(int board_size, const void* states, int state_fmt, int B, const float* packed,
+                                   float* pooled, float* logits, float* policy, float* value_pre, float* value,
+                                   int flags, int32_t* saturated, void* stream);
 
 /* Same network on an arbitrary batched graph: forward(x, edge_index, batch)  pv_network_gnn.py:53.
  *   x [num_nodes, F] f32;  csr_ptr [num_nodes+1] i32 / csr_src [E'] i32 / csr_w [E'] f32 : incoming edges of
@@ -171,7 +181,8 @@ typedef struct aqg_engine {
     uint8_t* hist_state72; uint16_t* hist_visits /* [G,max_plies,A] root child visit counts, dense by action */;
     uint8_t* hist_action /* [G,max_plies] */;
     /* counters [8] i32: 0 active slots, 1 finished games, 2 dead-end aborts, 3 next game index to hand out, 4 moves made
-     * (updated once per move) */
+     * (updated once per move), 5 fp16-range guard: set to 1 by a GNN evaluation of this engine that met a value outside fp16 range
+     * (see aqg_gcn_forward_boards_guarded; cleared by aqg_engine_reset only) */
     int32_t* counters;
     /* per-game statistics [G] i32 (summed by the host): network evaluations, simulations that ended on a terminal node */
     int32_t* stat_leaf_evals; int32_t* stat_terminal_sims;

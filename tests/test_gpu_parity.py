@@ -341,6 +341,81 @@ def test_gnn_fp16_range_guard(dev):
     assert int(visits.sum()) == 4 * 5
 
 
+def test_gnn_runtime_saturation_signal(dev):
+    """The fp16-split kernels report at RUN TIME when a value leaves fp16 range (the calibration boards cannot see every input).
+    Weight sets that pass the calibration -- all its boards have <= 10 walls in hand -- but leave the range on one crafted record
+    with 255 walls in hand (the network takes any feature value; pv_network_cnn.py:96 puts the count in a plane as it is):
+      A. a post-ReLU activation beyond 65504 (layer 1), B. a layer-2 linear-map output beyond it, negative (-> -inf -> 0 x inf = NaN
+      in the aggregation); and C. pooled features beyond it on every board (a layer-3 bias of 1e5: caught by the heads kernel, and
+      by the calibration already).
+    For each: the guarded C entry sets the caller's word on the crafted record and leaves it alone on an ordinary one; the module
+    notices, switches itself to the exact f32-input kernels and returns outputs that match the fp64 oracle; an engine searching
+    from the crafted root reports counters()['gnn_saturated']."""
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+    from oracle import gnn as og
+    lib = _lib.load()
+    g = U.golden("walk_9x9.npz")
+    normal = g["states"][[10, 400, 3000, 9000]].copy()
+    crafted = normal.copy()
+    crafted[:, 1] = 255                                    # walls in hand of the mover: feature 1 of every node
+    base = og.init_params(6)
+
+    def variant(which):
+        p = {k: v.copy() for k, v in base.items()}
+        if which == "A":
+            p["gcn_layers.0.lin.weight"][:, 1] = 200.0     # layer-1 activations ~ 8e3 at 10 walls, ~ 2e5 at 255
+        elif which == "B":
+            p["gcn_layers.0.lin.weight"][:, 1] = 20.0      # layer 1 stays in range (~ 2e4 at 255 walls) ...
+            p["gcn_layers.1.lin.weight"][:] = -0.05        # ... its 128 equal features sum to z ~ -1.3e5 in layer 2
+        else:
+            p["gcn_layers.2.bias"][:] = 1.0e5              # every pooled feature ~ 1e5 on every board: the heads' fp16 split overflows
+        return p
+
+    for which in ("A", "B", "C"):
+        params = variant(which)
+        model = GNNNetwork()
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        model = model.to(dev).eval()
+        pk = model.packed_weights(dev)
+        if which != "C":
+            assert model.gnn_flags(dev) == 0, which       # passes the calibration: the fast kernels are in use
+        else:
+            assert model.gnn_flags(dev) == _lib.GNN_EXACT_F32    # the calibration boards overflow as well: caught when the set is packed
+        word = torch.zeros((1,), dtype=torch.int32, device=dev)
+        pooled = torch.empty((4, 128), device=dev)
+        policy = torch.empty((4, 209), device=dev)
+        value = torch.empty((4,), device=dev)
+        for recs, want in ((normal, 0), (crafted, 1)):
+            word.zero_()
+            d = torch.from_numpy(recs).to(dev)
+            _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(d), 0, 4, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None,
+                                                          _lib.ptr(value), 0, _lib.ptr(word), _lib.stream_ptr(dev)), "guarded")
+            got = int(word.item())
+            if which == "C" and want == 0:
+                continue                                   # (see above)
+            assert got == want, (which, want, got)
+            if which != "C":
+                assert bool(torch.isfinite(policy).all()) and bool(torch.isfinite(value).all())   # activations are clamped, never inf / NaN
+        # the module: notices, switches, returns the network's outputs
+        ref = og.forward_states(params, crafted)
+        _, _, logits, vpre = model.forward_states(torch.from_numpy(crafted).to(dev), want_logits=True)
+        assert model.gnn_flags(dev) == _lib.GNN_EXACT_F32, which
+        sc = max(float(np.abs(ref["logits"]).max()), 1.0)
+        np.testing.assert_allclose(logits.cpu().numpy(), ref["logits"], atol=2e-5 * sc, rtol=2e-4)
+        np.testing.assert_allclose(vpre.cpu().numpy(), ref["value_pre"], atol=2e-5 * max(float(np.abs(ref["value_pre"]).max()), 1.0), rtol=2e-4)
+        # the engine: a search from the crafted roots on a fresh copy of the weights (fast kernels again) raises its counter
+        model2 = GNNNetwork()
+        model2.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        model2 = model2.to(dev).eval()
+        if model2.gnn_flags(dev) == 0:
+            eng = BatchedSelfPlay(model2, num_games=4, sims=3, record_history=False)
+            assert eng.counters()["gnn_saturated"] == 0
+            eng.search(crafted)
+            assert eng.counters()["gnn_saturated"] == 1, which
+
+
 def test_gnn_small_boards_forward_and_selfplay(dev):
     """The reference's smaller boards (constants.py:5-20) with the GNN evaluator: the any-size forward (plain kernels)
     against the fp64 oracle on 5x5 fixtures states, and a GNN-driven 5x5 self-play generation on the engine."""
