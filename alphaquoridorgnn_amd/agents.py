@@ -90,50 +90,65 @@ def argmax(collection):
     return collection.index(max(collection))
 
 
-class _Node:
-    __slots__ = ("state", "w", "n", "child_nodes")
+class _Tree:
+    """The reference's recursive Node.evaluate (agents.py:133-197) as an arena walked iteratively: nodes are rows of parallel
+    lists (state, w, n, first child, child count), children of a node are consecutive rows, one simulation = one descent that
+    records its path + one backup loop with the sign flipping per ply.  Same decisions in the same order, hence the same
+    consumption of the `random` stream (the goldens replay it): an untried child first, else the first maximum of UCB1
+    (agents.py:177-196); a playout at a childless node, which is expanded on its tenth visit (:153-163)."""
 
     def __init__(self, state):
-        self.state, self.w, self.n, self.child_nodes = state, 0, 0, None
+        self.state, self.w, self.n, self.first, self.count = [state], [0], [0], [-1], [0]
+        self.expand(0)
 
-    def expand(self):
-        self.child_nodes = [_Node(self.state.next(a)) for a in _legal(self.state)]
+    def expand(self, i):
+        self.first[i] = len(self.state)
+        for a in _legal(self.state[i]):
+            self.state.append(self.state[i].next(a))
+            self.w.append(0); self.n.append(0); self.first.append(-1); self.count.append(0)
+        self.count[i] = len(self.state) - self.first[i]
 
-    def next_child_node(self):
-        for c in self.child_nodes:                # an untried child first (agents.py:181-183)
-            if c.n == 0:
-                return c
-        t = sum(c.n for c in self.child_nodes)
-        ucb1 = [-c.w / c.n + 2 * (2 * math.log(t) / c.n) ** 0.5 for c in self.child_nodes]
-        return self.child_nodes[argmax(ucb1)]
+    def select(self, i):
+        kids = range(self.first[i], self.first[i] + self.count[i])
+        t = 0
+        for k in kids:
+            if self.n[k] == 0:
+                return k
+            t += self.n[k]
+        best, best_k = None, -1
+        for k in kids:
+            u = -self.w[k] / self.n[k] + 2 * (2 * math.log(t) / self.n[k]) ** 0.5
+            if best is None or u > best:          # strict: the first maximum wins, like list.index(max(...))
+                best, best_k = u, k
+        return best_k
 
-    def evaluate(self):
-        if self.state.is_done():                  # game over: the result itself (agents.py:143-150)
-            value = -1 if self.state.is_lose() else 0
-            self.w += value
-            self.n += 1
-            return value
-        if not self.child_nodes:                  # leaf: one random playout; expanded on the tenth visit (agents.py:153-163)
-            value = playout(self.state)
-            self.w += value
-            self.n += 1
-            if self.n == 10:
-                self.expand()
-            return value
-        value = -self.next_child_node().evaluate()   # interior: the child with the maximum UCB1 (agents.py:166-173)
-        self.w += value
-        self.n += 1
-        return value
+    def simulate(self):
+        path = [0]
+        while True:
+            i = path[-1]
+            st = self.state[i]
+            if st.is_done():
+                value = -1 if st.is_lose() else 0
+                break
+            if self.count[i] == 0:
+                value = playout(st)
+                if self.n[i] + 1 == 10:
+                    self.expand(i)
+                break
+            path.append(self.select(i))
+        for i in reversed(path):                  # value is the leaf's own view; every step up the path negates it (:167)
+            self.w[i] += value
+            self.n[i] += 1
+            value = -value
 
 
 def mcts_action(state, evaluations=100):
     """Plain Monte-Carlo tree search with random playouts; the most visited root action (agents.py:130-214)."""
-    root = _Node(state)
-    root.expand()
+    tree = _Tree(state)
     for _ in range(evaluations):
-        root.evaluate()
-    legal_actions = _legal(state)
-    return legal_actions[argmax([c.n for c in root.child_nodes])]
+        tree.simulate()
+    visits = tree.n[tree.first[0]:tree.first[0] + tree.count[0]]
+    return _legal(state)[argmax(visits)]
 
 
 if __name__ == '__main__':

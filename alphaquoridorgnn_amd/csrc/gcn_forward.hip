@@ -721,6 +721,9 @@ constexpr int F16_MAX_BITS = 0x477FE000;      // 65504.0f
 // and the NaNs with the sign bit set lie above everything else: 0 x (-inf) in an adjacency block gives such a NaN on this
 // hardware, and relu maps it to 0 without a trace.  Two v_max3 per four values each.
 __device__ __forceinline__ void track_range(const f32x4 v, int& imax, unsigned int& umax) {
+#ifdef AQG_NO_RANGE_GUARD      // timing-only build (tools/ab_trunk.py): what the guard costs
+    return;
+#endif
     const int i0 = __builtin_bit_cast(int, v[0]), i1 = __builtin_bit_cast(int, v[1]), i2 = __builtin_bit_cast(int, v[2]), i3 = __builtin_bit_cast(int, v[3]);
     imax = max(max(i0, i1), imax);
     imax = max(max(i2, i3), imax);

@@ -7,6 +7,7 @@
 //   aqg_host_shortest_path                   shortest_path_bfs       agents.py:27-41  (BFS over legal_actions_pos: jumps, static enemy)
 //   aqg_host_heuristic_eval                  heuristic_eval          agents.py:22-54  ((enemy's path - mover's path) / MAX_DIST_FROM_GOAL)
 //   aqg_host_alpha_beta_action               alpha_beta_action       agents.py:60-108 (depth-limited negamax, first best action wins)
+#include <limits>
 #include <cstdint>
 #include <cstring>
 #if defined(__HIPCC__) || defined(__HIP__)
@@ -127,7 +128,8 @@ double aqg_host_heuristic_eval(int board_size, const uint8_t* rec72, int max_dis
         case 3: return heuristic<3>(s, max_dist_from_goal);
         case 5: return heuristic<5>(s, max_dist_from_goal);
         case 7: return heuristic<7>(s, max_dist_from_goal);
-        default: return heuristic<9>(s, max_dist_from_goal);
+        case 9: return heuristic<9>(s, max_dist_from_goal);
+        default: return std::numeric_limits<double>::quiet_NaN();      // unsupported board size: an error value, like the siblings' -1 / -2
     }
 }
 

@@ -113,22 +113,22 @@ class State:
     def rotate_walls(self):
         self.walls = list(self.walls)[::-1]
 
+    @classmethod
+    def from_record(cls, rec):
+        """State of a state72 record (the layout in include/aqgnn.h)."""
+        N = int(rec[70])
+        nw = (N - 1) ** 2
+        return cls(board_size=N, player=[int(rec[0]), int(rec[1])], enemy=[int(rec[2]), int(rec[3])],
+                   walls=[int(x) for x in rec[4:4 + nw]], plies_played=int(rec[68]) | (int(rec[69]) << 8))
+
     def next(self, action):
-        N = self.N
-        action = int(action)
-        state = State(board_size=N, player=list(self.player), enemy=list(self.enemy), walls=list(self.walls),
-                      plies_played=self.plies_played + 1)
-        if action < N ** 2:
-            state.player[0] = action
-        elif action < N ** 2 + (N - 1) ** 2:
-            state.walls[action - N ** 2] = 1
-            state.player[1] -= 1
-        else:
-            state.walls[action - N ** 2 - (N - 1) ** 2] = 2
-            state.player[1] -= 1
-        state.rotate_walls()
-        state.player, state.enemy = state.enemy, state.player
-        return state
+        """game_logic.py:366-391 -- move the pawn or set the wall, turn the board by 180 degrees, swap the players -- by the rule
+        header the kernels compile, in its host instantiation (aqg_host_next): one transition code for device and host."""
+        import ctypes
+        rec, out = self.record(), np.empty(STATE72, dtype=np.uint8)
+        if _lib.load().aqg_host_next(self.N, rec.ctypes.data_as(ctypes.c_void_p), int(action), out.ctypes.data_as(ctypes.c_void_p)) != 0:
+            raise ValueError(f"action {action} is not an action of a {self.N}x{self.N} board")
+        return State.from_record(out)
 
     # -- board-walking queries: HIP kernel, batch of one
     def record(self):
