@@ -741,8 +741,8 @@ __device__ __forceinline__ void report_saturation(bool lane_saw_it, int32_t* __r
 
 // A wave owns JT 16-column feature tiles: JT = 2 -> 4 waves per board, JT = 1 -> 8 waves per board.
 // fp16 planes of four consecutive features of one node: hi (11 bits) + lo (next 11 bits) = 22 mantissa bits
-template <int NWV>
-__device__ __forceinline__ void store_split4(TrunkSmemM<NWV>& sm, int off, const f32x4 v) {
+template <class SM>
+__device__ __forceinline__ void store_split4(SM& sm, int off, const f32x4 v) {
 #ifdef AQG_ABL_EPI
     asm volatile("" :: "v"(v), "v"(off));
 #else
@@ -776,8 +776,8 @@ __device__ __forceinline__ void split_tile_piece(const f32x4 z, int m, int piece
 // U = Q W~ for this wave's columns: six 16-row tiles (tile 5 = row 80 repeated) x four 32-deep k blocks, A fragments
 // double-buffered from the planes, three fp16 terms per block (smallest first).  The fp16 split of tile m - 1 (six vector
 // instructions per feature tile) is issued between the MFMA groups of tile m: it costs no time of its own.
-template <int JT>
-__device__ __forceinline__ void linear_split(const TrunkSmemM<8 / JT>& sm, const u32x4 (&Bf)[2][JT][4], int lane, u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3]) {
+template <int JT, class SM>
+__device__ __forceinline__ void linear_split(const SM& sm, const u32x4 (&Bf)[2][JT][4], int lane, u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3]) {
     const int c = lane & 15, q = lane >> 4;
     u32x4 cur[2], nxt[2];
     auto frag_off = [&](int step) -> int {                  // step = m*4 + kb
@@ -849,8 +849,8 @@ __device__ __forceinline__ void request_bias(f32x4 (&out)[6][JT], __amdgpu_buffe
 // The blocks of a node tile are consecutive (a dependent 16x16x32 chain issues at the full rate), so tile nt is complete while
 // tile nt + 1 is still on the matrix pipe: its relu / split / stores are vector and LDS work issued under those MFMAs.
 // (No plane byte is read here: the caller has passed the barrier behind the linear map, the stores are free to go.)
-template <int JT, bool LAST>
-__device__ __forceinline__ void aggregate_store(TrunkSmemM<8 / JT>& sm, const unsigned int (&AF)[AF_BLOCKS][64][4], u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], f32x4 (&out)[6][JT], int wave, int lane,
+template <int JT, bool LAST, class SM>
+__device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)[AF_BLOCKS][64][4], u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], f32x4 (&out)[6][JT], int wave, int lane,
                                                 const int (&toff)[3], __amdgpu_buffer_rsrc_t pooled_rs, int pooled_soff, int32_t* __restrict__ saturated,
                                                 float* pooled_lds = nullptr) {
     constexpr int AHEAD = 3;
@@ -950,8 +950,8 @@ __device__ __forceinline__ float lane_sel(uint64_t m, float a) {
 // rows of G' (lane = node; k-slots of q = 0 / 2 read the hi half, q = 1 the lo half, q = 3 meets zero weight slots), accumulated on
 // the bias rows.  The result already has the store layout (lane = node, 4 consecutive features): relu, fp16 split, plane stores.
 // 6 MFMAs per wave and feature tile where the linear-first form needed 6 + 20 (X0 W1, then the 128-wide banded aggregation).
-template <int JT>
-__device__ __forceinline__ void layer1_store(TrunkSmemM<8 / JT>& sm, const unsigned short (&G)[81][16], const u32x4 (&w1f)[JT], f32x4 (&out)[6][JT],
+template <int JT, class SM>
+__device__ __forceinline__ void layer1_store(SM& sm, const unsigned short (&G)[81][16], const u32x4 (&w1f)[JT], f32x4 (&out)[6][JT],
                                              int wave, int lane, int32_t* __restrict__ saturated) {
     const int c = lane & 15, q = lane >> 4;
     int imax = 0;
@@ -1102,6 +1102,186 @@ __device__ __forceinline__ void fused_heads_512(FusedHeadsScratch& sc, __amdgpu_
     }
 }
 
+// The lane index, re-derived from the execution mask (two v_mbcnt) wherever it is needed instead of being kept in a register across
+// the board loop (at the 128-register cap the allocator spilled it and reloaded it behind an s_waitcnt vmcnt(0)).
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+// ---- per-board inputs.  decode: the record becomes wave-uniform scalars (the wall masks by ballot over the 64 wall bytes).
+__device__ __forceinline__ void trunk_decode(int fmt, uint32_t r0, uint32_t r1, uint64_t& hw, uint64_t& vw, uint32_t& hd) {
+    if (fmt == 0) {
+        hw = __ballot((r0 & 1u) != 0);                               // wall byte: bit0 H, bit1 V
+        vw = __ballot((r0 & 2u) != 0);
+        hd = __builtin_amdgcn_readfirstlane(r1);
+    } else {
+        // (readlane returns a SIGNED int: without the uint32_t cast a wall in slot 31 sign-extends into slots 32..63 --
+        //  a round-1 bug that only the in-engine evaluation path could hit; tests/test_gpu_parity.py pins it now)
+        hw = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(r0, 0) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(r0, 1) << 32);
+        vw = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(r0, 2) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(r0, 3) << 32);
+        hd = (uint32_t)__builtin_amdgcn_readlane(r0, 4);
+    }
+}
+// deg - 1 = U + D + L + R of every node as three bit planes (bit-sliced adder on the scalar unit; c1 excludes c3, so
+// c1 + c2 + c3 <= 2 and b2 = c1 & c2), lo = nodes 0..63, hi = nodes 64..80
+struct Planes { uint64_t b0l, b1l, b2l, b0h, b1h, b2h; };
+__device__ __forceinline__ Planes degree_planes(const Open& op) {
+    Planes p;
+    {
+        const uint64_t x = op.U.lo ^ op.D.lo, c1 = op.U.lo & op.D.lo, y = op.L.lo ^ op.R.lo, c2 = op.L.lo & op.R.lo, c3 = x & y;
+        p.b0l = x ^ y; p.b1l = c1 ^ c2 ^ c3; p.b2l = c1 & c2;
+    }
+    {
+        const uint64_t x = op.U.hi ^ op.D.hi, c1 = op.U.hi & op.D.hi, y = op.L.hi ^ op.R.hi, c2 = op.L.hi & op.R.hi, c3 = x & y;
+        p.b0h = x ^ y; p.b1h = c1 ^ c2 ^ c3; p.b2h = c1 & c2;
+    }
+    return p;
+}
+// build_inputs: everything a board's layers read from LDS besides the planes, into buffer `par` --
+//  (1) layer-1 input, aggregated first (GCNConv is linear before its ReLU: A_hat (X W) = (A_hat X) W, and X has 6 columns where
+//      X W has 128):  G'[n][f] = sum_{k in N[n]} X0[k][f] / sqrt(deg k)  (the 1 / sqrt(deg n) half of the symmetric norm cancels
+//      against the sqrt(deg) scale of the plane image).  Wave f < 6 owns feature f for all 81 nodes (lane = node `lane`, lanes
+//      < 17 also node 64 + lane): the feature is a wave-uniform bitboard times a scalar (pv_network_cnn.py:88-114: pawn tile,
+//      walls in hand, enemy pawn tile in the enemy's frame, its walls, horizontal / vertical wall at the tile's slot), so x = one
+//      v_cndmask; x / sqrt(deg) goes through 384 bytes of the wave's own LDS scratch to reach the four neighbours (no other
+//      wave is involved: no barrier), the sum is split into fp16 hi / lo and stored as the B operand rows of layer 1;
+//  (2) the banded adjacency fragments of layers 2 and 3.
+// Called for the first board of a workgroup before the loop, and for board b + 1 under board b's layer 3 (the buffers of the
+// other parity were last read a whole board ago: four barriers back).
+template <int NWV>
+__device__ __forceinline__ void trunk_build_inputs(unsigned short (&G16)[81][16], unsigned int (&AF)[AF_BLOCKS][64][4], float* __restrict__ Yw,
+                                               unsigned short (&degv)[NWV == 4 ? 3 : 2][32], int wave, uint64_t hw, uint64_t vw, uint32_t hd, int what) {
+constexpr int N = 9, V = 81, NSLOT = NWV == 4 ? 3 : 2;
+    const Open op = make_open<N>(hw, vw);
+    const Planes pl = degree_planes(op);
+    if (what & 1) {
+        const int ppos = hd & 0xff, pwl = (hd >> 8) & 0xff, epos = (hd >> 16) & 0xff, ewl = hd >> 24;
+        const BB shb = spread_slots<N>(hw), svb = spread_slots<N>(vw);
+#pragma unroll
+        for (int it = 0; it < (6 + NWV - 1) / NWV; ++it) {
+            const int f = __builtin_amdgcn_readfirstlane(wave + NWV * it);   // wave-uniform, and known to be: the masks below stay scalar
+            if (f < 6) {
+                BB m = mask_all<N>();
+                float sc = 1.f;
+                if (f == 0) m = bb_bit(ppos);
+                else if (f == 1) sc = (float)pwl;
+                else if (f == 2) m = bb_bit(epos);
+                else if (f == 3) sc = (float)ewl;
+                else if (f == 4) m = shb;
+                else m = svb;
+                const int ln = fresh_lane(), l1 = min(ln, 16);
+                const float dnv0 = dinv_of_dm(lane_bit(pl.b0l) | (lane_bit(pl.b1l) << 1) | (lane_bit(pl.b2l) << 2));
+                const float dnv1 = dinv_of_dm(lane_bit(pl.b0h) | (lane_bit(pl.b1h) << 1) | (lane_bit(pl.b2h) << 2));
+                const float y0 = lane_sel(m.lo, sc) * dnv0, y1 = lane_sel(m.hi, sc) * dnv1;
+                                Yw[ln] = y0;
+                if (ln < 17) Yw[64 + ln] = y1;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // (an edge that is open leads to a node of the board: clamped addresses are only ever read by lanes that discard them)
+                const float nu0 = Yw[max(ln - 9, 0)], nd0 = Yw[ln + 9], nl0 = Yw[max(ln - 1, 0)], nr0 = Yw[ln + 1];
+                const float nu1 = Yw[55 + l1], nd1 = Yw[73 + l1], nl1 = Yw[63 + l1], nr1 = Yw[65 + l1];
+                const float g0 = (((y0 + lane_sel(op.U.lo, nu0)) + lane_sel(op.D.lo, nd0)) + lane_sel(op.L.lo, nl0)) + lane_sel(op.R.lo, nr0);
+                const float g1 = (((y1 + lane_sel(op.U.hi, nu1)) + lane_sel(op.D.hi, nd1)) + lane_sel(op.L.hi, nl1)) + lane_sel(op.R.hi, nr1);
+                const _Float16 h0 = (_Float16)g0, h1 = (_Float16)g1;
+                const _Float16 e0 = (_Float16)(g0 - (float)h0), e1 = (_Float16)(g1 - (float)h1);
+                G16[ln][f] = __builtin_bit_cast(unsigned short, h0);
+                G16[ln][8 + f] = __builtin_bit_cast(unsigned short, e0);
+                if (ln < 17) {
+                    G16[64 + ln][f] = __builtin_bit_cast(unsigned short, h1);
+                    G16[64 + ln][8 + f] = __builtin_bit_cast(unsigned short, e1);
+                }
+            }
+        }
+    }
+    if (what & 2) {
+        const int lane = fresh_lane();
+        // the four open-edge boards as 3 x 32-bit words each (word w = nodes 32 w .. 32 w + 31), selected arithmetically
+        // (scalars, not an array: an indexed local array would live in scratch memory)
+        const uint32_t u0 = (uint32_t)op.U.lo, u1 = (uint32_t)(op.U.lo >> 32), u2 = (uint32_t)op.U.hi;
+        const uint32_t d0w = (uint32_t)op.D.lo, d1w = (uint32_t)(op.D.lo >> 32), d2w = (uint32_t)op.D.hi;
+        const uint32_t l0 = (uint32_t)op.L.lo, l1 = (uint32_t)(op.L.lo >> 32), l2 = (uint32_t)op.L.hi;
+        const uint32_t r0w = (uint32_t)op.R.lo, r1w = (uint32_t)(op.R.lo >> 32), r2w = (uint32_t)op.R.hi;
+        auto sel3 = [](uint32_t a0, uint32_t a1, uint32_t a2, int w) -> uint32_t { const uint32_t a = w == 0 ? a0 : a1; return w == 2 ? a2 : a; };
+        auto open_word = [&](int dir, int w) -> uint32_t {
+            return dir == 0 ? sel3(u0, u1, u2, w) : dir == 1 ? sel3(d0w, d1w, d2w, w) : dir == 2 ? sel3(l0, l1, l2, w) : sel3(r0w, r1w, r2w, w);
+        };
+        // ten adjacency blocks over the waves:   8 waves: w0 {8}  w1 {9}  w2 {0,6}  w3 {1,7}  w4..7 {2..5}      4 waves: w0 {0,4}  w1 {1,5}  w2 {2,6,8}  w3 {3,7,9}
+        auto slot_block = [&](int it) -> int {                           // wave-uniform
+            if (NWV == 8) return it == 0 ? (wave >= 2 ? wave - 2 : wave + 8) : ((wave == 2 || wave == 3) ? wave + 4 : AF_BLOCKS);
+            return it < 2 ? wave + 4 * it : (wave >= 2 ? wave + 6 : AF_BLOCKS);
+        };
+        // step 1: the fp16 values CQ / deg(k) of the 32 source nodes of each block's k range, through this wave's own LDS
+        //         scratch (lane l < 32 = node 32 kb + l; the word of the open-edge boards is wave-uniform)
+#pragma unroll
+        for (int it = 0; it < NSLOT; ++it) {
+            const int blk = slot_block(it);
+            if (blk < AF_BLOCKS && lane < 32) {
+                const int kb = (AF_KB_PACK >> (2 * blk)) & 3;
+                const int l = fresh_lane();
+                const uint32_t deg = 1u + ((open_word(0, kb) >> l) & 1u) + ((open_word(1, kb) >> l) & 1u) +
+                                     ((open_word(2, kb) >> l) & 1u) + ((open_word(3, kb) >> l) & 1u);
+                // fp16 of CQ / deg = 0.9375, 0.46875, 0.3125, 0.234375, 0.1875 (all exact)
+                const uint32_t val = deg == 1u ? 0x3B80u : deg == 2u ? 0x3780u : deg == 3u ? 0x3500u : deg == 4u ? 0x3380u : 0x3200u;
+                degv[it][l] = (unsigned short)((32 * kb + l < V) ? val : 0u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // step 2: the fragments.  k-slot e of lane (c, q) is node 32 kb + 16 (e >> 2) + 4 q + (e & 3); entry = CQ / deg(k) where
+        //         node n = 16 nt + c has k in its closed neighbourhood, else 0
+#pragma unroll
+        for (int it = 0; it < NSLOT; ++it) {
+            const int blk = slot_block(it);
+            if (blk < AF_BLOCKS) {
+                const int kb = (AF_KB_PACK >> (2 * blk)) & 3, nt = (AF_NT_PACK >> (3 * blk)) & 7;
+                const int ln = fresh_lane();      // no per-slot lane constant is kept alive (spilled) across the loop
+                const int n = 16 * nt + (ln & 15), q = ln >> 4;
+                u32x4 fr = (u32x4){0u, 0u, 0u, 0u};
+                if (n < V) {
+                    const int w = nt >> 1, sft = n & 31;                 // n >> 5 == nt >> 1: the word is wave-uniform
+                    // window of row n of (A + I) around the diagonal: bit (k - n + 9), k = n-9 (U), n-1 (L), n, n+1 (R), n+9 (D)
+                    const uint32_t win = (1u << 9) | ((open_word(0, w) >> sft) & 1u) | (((open_word(2, w) >> sft) & 1u) << 8) |
+                                         (((open_word(3, w) >> sft) & 1u) << 10) | (((open_word(1, w) >> sft) & 1u) << 18);
+                    const int d0 = 32 * kb + 4 * q - n + 9;              // window bit of k-slot e = 0; e = 4 sits 16 higher
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u32x2 dv = *reinterpret_cast<const u32x2*>(&degv[it][16 * h + 4 * q]);   // nodes 32 kb + 16 h + 4 q + 0..3
+                        const int d = d0 + 16 * h;
+                        uint32_t nib = (d >= 0) ? (win >> min(d, 31)) : (win << min(-d, 4));
+                        nib &= 0xFu;
+                        const uint32_t t2 = nib | (nib << 15);           // b0 -> bit 0, b1 -> bit 16, b2 -> bit 2, b3 -> bit 18
+                        fr[2 * h] = ((t2 & 0x00010001u) * 0xFFFFu) & dv[0];          // 0xFFFF in each selected half
+                        fr[2 * h + 1] = (((t2 >> 2) & 0x00010001u) * 0xFFFFu) & dv[1];
+                    }
+                }
+                *reinterpret_cast<u32x4*>(&AF[blk][ln][0]) = fr;
+            }
+        }
+    }
+}
+
+
+// Byte offset of a lane's rows in a bias table, (deg - 1) * 512 + 16 q, for its node 16 nt + c of every node tile (first row for
+// the padding nodes 81..95: their plane bits are zero), two node tiles per register; deg - 1 stays readable above bit 9 (the mean
+// pool's 1 / sqrt(deg)).  Straight from the record's degree bit planes: nothing here waits for a barrier.
+__device__ __forceinline__ void trunk_bias_offsets(uint64_t hw, uint64_t vw, int c, int q, int (&toff)[3]) {
+    const Planes pl = degree_planes(make_open<9>(hw, vw));
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) {
+        const uint32_t w0 = nt < 4 ? (uint32_t)(pl.b0l >> (32 * (nt >> 1))) : (uint32_t)pl.b0h;
+        const uint32_t w1 = nt < 4 ? (uint32_t)(pl.b1l >> (32 * (nt >> 1))) : (uint32_t)pl.b1h;
+        const uint32_t w2 = nt < 4 ? (uint32_t)(pl.b2l >> (32 * (nt >> 1))) : (uint32_t)pl.b2h;
+        const int sft = (nt < 4 ? 16 * (nt & 1) : 16 * (nt - 4)) + c;
+        const int dm = (int)(((w0 >> sft) & 1u) | (((w1 >> sft) & 1u) << 1) | (((w2 >> sft) & 1u) << 2));
+        const int o = dm * (HID * 4) + 16 * q;
+        toff[nt >> 1] = (nt & 1) ? (toff[nt >> 1] | (o << 16)) : o;
+    }
+}
+
 // (hipcc's second launch-bound argument is waves per SIMD: workgroups per CU x waves per workgroup / 4 SIMDs)
 template <int JT, int WGS_PER_CU, bool FUSE = false>
 __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trunk_boards_mm_kernel(const void* __restrict__ states, int fmt, int B,
@@ -1141,11 +1321,6 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     // reloaded it behind an s_waitcnt vmcnt(0) that drained the weight prefetches): the wave index is a scalar, the lane index
     // is re-derived from the execution mask (two v_mbcnt) wherever it is needed.
     const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    auto fresh_lane = []() -> int {
-        int l;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-        return l;
-    };
     int wave = wave0;
 
     int b = blockIdx.x;
@@ -1183,156 +1358,9 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pooled, 0, B * (HID * 4), 0x00020000);
 
-    // ---- per-board inputs.  decode: the record becomes wave-uniform scalars (the wall masks by ballot over the 64 wall bytes).
-    auto decode = [&](uint32_t r0, uint32_t r1, uint64_t& hw, uint64_t& vw, uint32_t& hd) {
-        if (fmt == 0) {
-            hw = __ballot((r0 & 1u) != 0);                               // wall byte: bit0 H, bit1 V
-            vw = __ballot((r0 & 2u) != 0);
-            hd = __builtin_amdgcn_readfirstlane(r1);
-        } else {
-            // (readlane returns a SIGNED int: without the uint32_t cast a wall in slot 31 sign-extends into slots 32..63 --
-            //  a round-1 bug that only the in-engine evaluation path could hit; tests/test_gpu_parity.py pins it now)
-            hw = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(r0, 0) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(r0, 1) << 32);
-            vw = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(r0, 2) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(r0, 3) << 32);
-            hd = (uint32_t)__builtin_amdgcn_readlane(r0, 4);
-        }
-    };
-    // deg - 1 = U + D + L + R of every node as three bit planes (bit-sliced adder on the scalar unit; c1 excludes c3, so
-    // c1 + c2 + c3 <= 2 and b2 = c1 & c2), lo = nodes 0..63, hi = nodes 64..80
-    struct Planes { uint64_t b0l, b1l, b2l, b0h, b1h, b2h; };
-    auto degree_planes = [](const Open& op) -> Planes {
-        Planes p;
-        {
-            const uint64_t x = op.U.lo ^ op.D.lo, c1 = op.U.lo & op.D.lo, y = op.L.lo ^ op.R.lo, c2 = op.L.lo & op.R.lo, c3 = x & y;
-            p.b0l = x ^ y; p.b1l = c1 ^ c2 ^ c3; p.b2l = c1 & c2;
-        }
-        {
-            const uint64_t x = op.U.hi ^ op.D.hi, c1 = op.U.hi & op.D.hi, y = op.L.hi ^ op.R.hi, c2 = op.L.hi & op.R.hi, c3 = x & y;
-            p.b0h = x ^ y; p.b1h = c1 ^ c2 ^ c3; p.b2h = c1 & c2;
-        }
-        return p;
-    };
-    // build_inputs: everything a board's layers read from LDS besides the planes, into buffer `par` --
-    //  (1) layer-1 input, aggregated first (GCNConv is linear before its ReLU: A_hat (X W) = (A_hat X) W, and X has 6 columns where
-    //      X W has 128):  G'[n][f] = sum_{k in N[n]} X0[k][f] / sqrt(deg k)  (the 1 / sqrt(deg n) half of the symmetric norm cancels
-    //      against the sqrt(deg) scale of the plane image).  Wave f < 6 owns feature f for all 81 nodes (lane = node `lane`, lanes
-    //      < 17 also node 64 + lane): the feature is a wave-uniform bitboard times a scalar (pv_network_cnn.py:88-114: pawn tile,
-    //      walls in hand, enemy pawn tile in the enemy's frame, its walls, horizontal / vertical wall at the tile's slot), so x = one
-    //      v_cndmask; x / sqrt(deg) goes through 384 bytes of the wave's own LDS scratch to reach the four neighbours (no other
-    //      wave is involved: no barrier), the sum is split into fp16 hi / lo and stored as the B operand rows of layer 1;
-    //  (2) the banded adjacency fragments of layers 2 and 3.
-    // Called for the first board of a workgroup before the loop, and for board b + 1 under board b's layer 3 (the buffers of the
-    // other parity were last read a whole board ago: four barriers back).
+    auto decode = [&](uint32_t r0, uint32_t r1, uint64_t& hw, uint64_t& vw, uint32_t& hd) { trunk_decode(fmt, r0, r1, hw, vw, hd); };
     auto build_inputs = [&](int par, uint64_t hw, uint64_t vw, uint32_t hd, int what) {
-        const Open op = make_open<N>(hw, vw);
-        const Planes pl = degree_planes(op);
-        if (what & 1) {
-            const int ppos = hd & 0xff, pwl = (hd >> 8) & 0xff, epos = (hd >> 16) & 0xff, ewl = hd >> 24;
-            const BB shb = spread_slots<N>(hw), svb = spread_slots<N>(vw);
-#pragma unroll
-            for (int it = 0; it < (6 + NWV - 1) / NWV; ++it) {
-                const int f = __builtin_amdgcn_readfirstlane(wave + NWV * it);   // wave-uniform, and known to be: the masks below stay scalar
-                if (f < 6) {
-                    BB m = mask_all<N>();
-                    float sc = 1.f;
-                    if (f == 0) m = bb_bit(ppos);
-                    else if (f == 1) sc = (float)pwl;
-                    else if (f == 2) m = bb_bit(epos);
-                    else if (f == 3) sc = (float)ewl;
-                    else if (f == 4) m = shb;
-                    else m = svb;
-                    const int ln = fresh_lane(), l1 = min(ln, 16);
-                    const float dnv0 = dinv_of_dm(lane_bit(pl.b0l) | (lane_bit(pl.b1l) << 1) | (lane_bit(pl.b2l) << 2));
-                    const float dnv1 = dinv_of_dm(lane_bit(pl.b0h) | (lane_bit(pl.b1h) << 1) | (lane_bit(pl.b2h) << 2));
-                    const float y0 = lane_sel(m.lo, sc) * dnv0, y1 = lane_sel(m.hi, sc) * dnv1;
-                    float* Yw = sm.Y[wave];
-                    Yw[ln] = y0;
-                    if (ln < 17) Yw[64 + ln] = y1;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    // (an edge that is open leads to a node of the board: clamped addresses are only ever read by lanes that discard them)
-                    const float nu0 = Yw[max(ln - 9, 0)], nd0 = Yw[ln + 9], nl0 = Yw[max(ln - 1, 0)], nr0 = Yw[ln + 1];
-                    const float nu1 = Yw[55 + l1], nd1 = Yw[73 + l1], nl1 = Yw[63 + l1], nr1 = Yw[65 + l1];
-                    const float g0 = (((y0 + lane_sel(op.U.lo, nu0)) + lane_sel(op.D.lo, nd0)) + lane_sel(op.L.lo, nl0)) + lane_sel(op.R.lo, nr0);
-                    const float g1 = (((y1 + lane_sel(op.U.hi, nu1)) + lane_sel(op.D.hi, nd1)) + lane_sel(op.L.hi, nl1)) + lane_sel(op.R.hi, nr1);
-                    const _Float16 h0 = (_Float16)g0, h1 = (_Float16)g1;
-                    const _Float16 e0 = (_Float16)(g0 - (float)h0), e1 = (_Float16)(g1 - (float)h1);
-                    sm.G16[par][ln][f] = __builtin_bit_cast(unsigned short, h0);
-                    sm.G16[par][ln][8 + f] = __builtin_bit_cast(unsigned short, e0);
-                    if (ln < 17) {
-                        sm.G16[par][64 + ln][f] = __builtin_bit_cast(unsigned short, h1);
-                        sm.G16[par][64 + ln][8 + f] = __builtin_bit_cast(unsigned short, e1);
-                    }
-                }
-            }
-        }
-        if (what & 2) {
-            const int lane = fresh_lane();
-            // the four open-edge boards as 3 x 32-bit words each (word w = nodes 32 w .. 32 w + 31), selected arithmetically
-            // (scalars, not an array: an indexed local array would live in scratch memory)
-            const uint32_t u0 = (uint32_t)op.U.lo, u1 = (uint32_t)(op.U.lo >> 32), u2 = (uint32_t)op.U.hi;
-            const uint32_t d0w = (uint32_t)op.D.lo, d1w = (uint32_t)(op.D.lo >> 32), d2w = (uint32_t)op.D.hi;
-            const uint32_t l0 = (uint32_t)op.L.lo, l1 = (uint32_t)(op.L.lo >> 32), l2 = (uint32_t)op.L.hi;
-            const uint32_t r0w = (uint32_t)op.R.lo, r1w = (uint32_t)(op.R.lo >> 32), r2w = (uint32_t)op.R.hi;
-            auto sel3 = [](uint32_t a0, uint32_t a1, uint32_t a2, int w) -> uint32_t { const uint32_t a = w == 0 ? a0 : a1; return w == 2 ? a2 : a; };
-            auto open_word = [&](int dir, int w) -> uint32_t {
-                return dir == 0 ? sel3(u0, u1, u2, w) : dir == 1 ? sel3(d0w, d1w, d2w, w) : dir == 2 ? sel3(l0, l1, l2, w) : sel3(r0w, r1w, r2w, w);
-            };
-            // ten adjacency blocks over the waves:   8 waves: w0 {8}  w1 {9}  w2 {0,6}  w3 {1,7}  w4..7 {2..5}      4 waves: w0 {0,4}  w1 {1,5}  w2 {2,6,8}  w3 {3,7,9}
-            auto slot_block = [&](int it) -> int {                           // wave-uniform
-                if (NWV == 8) return it == 0 ? (wave >= 2 ? wave - 2 : wave + 8) : ((wave == 2 || wave == 3) ? wave + 4 : AF_BLOCKS);
-                return it < 2 ? wave + 4 * it : (wave >= 2 ? wave + 6 : AF_BLOCKS);
-            };
-            // step 1: the fp16 values CQ / deg(k) of the 32 source nodes of each block's k range, through this wave's own LDS
-            //         scratch (lane l < 32 = node 32 kb + l; the word of the open-edge boards is wave-uniform)
-#pragma unroll
-            for (int it = 0; it < NSLOT; ++it) {
-                const int blk = slot_block(it);
-                if (blk < AF_BLOCKS && lane < 32) {
-                    const int kb = (AF_KB_PACK >> (2 * blk)) & 3;
-                    const int l = fresh_lane();
-                    const uint32_t deg = 1u + ((open_word(0, kb) >> l) & 1u) + ((open_word(1, kb) >> l) & 1u) +
-                                         ((open_word(2, kb) >> l) & 1u) + ((open_word(3, kb) >> l) & 1u);
-                    // fp16 of CQ / deg = 0.9375, 0.46875, 0.3125, 0.234375, 0.1875 (all exact)
-                    const uint32_t val = deg == 1u ? 0x3B80u : deg == 2u ? 0x3780u : deg == 3u ? 0x3500u : deg == 4u ? 0x3380u : 0x3200u;
-                    sm.degv[wave][it][l] = (unsigned short)((32 * kb + l < V) ? val : 0u);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // step 2: the fragments.  k-slot e of lane (c, q) is node 32 kb + 16 (e >> 2) + 4 q + (e & 3); entry = CQ / deg(k) where
-            //         node n = 16 nt + c has k in its closed neighbourhood, else 0
-#pragma unroll
-            for (int it = 0; it < NSLOT; ++it) {
-                const int blk = slot_block(it);
-                if (blk < AF_BLOCKS) {
-                    const int kb = (AF_KB_PACK >> (2 * blk)) & 3, nt = (AF_NT_PACK >> (3 * blk)) & 7;
-                    const int ln = fresh_lane();      // no per-slot lane constant is kept alive (spilled) across the loop
-                    const int n = 16 * nt + (ln & 15), q = ln >> 4;
-                    u32x4 fr = (u32x4){0u, 0u, 0u, 0u};
-                    if (n < V) {
-                        const int w = nt >> 1, sft = n & 31;                 // n >> 5 == nt >> 1: the word is wave-uniform
-                        // window of row n of (A + I) around the diagonal: bit (k - n + 9), k = n-9 (U), n-1 (L), n, n+1 (R), n+9 (D)
-                        const uint32_t win = (1u << 9) | ((open_word(0, w) >> sft) & 1u) | (((open_word(2, w) >> sft) & 1u) << 8) |
-                                             (((open_word(3, w) >> sft) & 1u) << 10) | (((open_word(1, w) >> sft) & 1u) << 18);
-                        const int d0 = 32 * kb + 4 * q - n + 9;              // window bit of k-slot e = 0; e = 4 sits 16 higher
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const u32x2 dv = *reinterpret_cast<const u32x2*>(&sm.degv[wave][it][16 * h + 4 * q]);   // nodes 32 kb + 16 h + 4 q + 0..3
-                            const int d = d0 + 16 * h;
-                            uint32_t nib = (d >= 0) ? (win >> min(d, 31)) : (win << min(-d, 4));
-                            nib &= 0xFu;
-                            const uint32_t t2 = nib | (nib << 15);           // b0 -> bit 0, b1 -> bit 16, b2 -> bit 2, b3 -> bit 18
-                            fr[2 * h] = ((t2 & 0x00010001u) * 0xFFFFu) & dv[0];          // 0xFFFF in each selected half
-                            fr[2 * h + 1] = (((t2 >> 2) & 0x00010001u) * 0xFFFFu) & dv[1];
-                        }
-                    }
-                    *reinterpret_cast<u32x4*>(&sm.AF[par][blk][ln][0]) = fr;
-                }
-            }
-        }
+        trunk_build_inputs<NWV>(sm.G16[par], sm.AF[par], sm.Y[wave], sm.degv[wave], wave, hw, vw, hd, what);
     };
 
     AQG_STAMP_DECL
@@ -1350,26 +1378,11 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
 #pragma unroll
         for (int j = 0; j < JT; ++j) w1f[j] = load_frag16(rs, lane * 16, (int)(PackedLayout::WH1 * sizeof(float)) + (wave * JT + j) * (64 * 16));
         __builtin_amdgcn_sched_barrier(0);
-        // byte offset of this lane's rows in a bias table, (deg - 1) * 512 + 16 q, for its node 16 nt + c of every node tile (first
-        // row for the padding nodes 81..95: their plane bits are zero), two node tiles per register; deg - 1 stays readable above
-        // bit 9 (the mean pool's 1 / sqrt(deg)).  Straight from the record's bit planes: nothing here waits for a barrier.
         int toff[3];
         uint64_t hw, vw;
         uint32_t hd;
         decode(rec0, rec1, hw, vw, hd);
-        {
-            const Planes pl = degree_planes(make_open<N>(hw, vw));
-#pragma unroll
-            for (int nt = 0; nt < 6; ++nt) {
-                const uint32_t w0 = nt < 4 ? (uint32_t)(pl.b0l >> (32 * (nt >> 1))) : (uint32_t)pl.b0h;
-                const uint32_t w1 = nt < 4 ? (uint32_t)(pl.b1l >> (32 * (nt >> 1))) : (uint32_t)pl.b1h;
-                const uint32_t w2 = nt < 4 ? (uint32_t)(pl.b2l >> (32 * (nt >> 1))) : (uint32_t)pl.b2h;
-                const int sft = (nt < 4 ? 16 * (nt & 1) : 16 * (nt - 4)) + c;
-                const int dm = (int)(((w0 >> sft) & 1u) | (((w1 >> sft) & 1u) << 1) | (((w2 >> sft) & 1u) << 2));
-                const int o = dm * (HID * 4) + 16 * q;
-                toff[nt >> 1] = (nt & 1) ? (toff[nt >> 1] | (o << 16)) : o;
-            }
-        }
+        trunk_bias_offsets(hw, vw, c, q, toff);
         f32x4 out[6][JT];
         u32x4 zh[JT][3], zl[JT][3];
         request_bias<JT>(out, rs, 0, toff, wave);                            // lands under the input build + barrier
@@ -1467,6 +1480,132 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
         o[16] = (unsigned long long)st_n;
     }
 #endif
+    AQG_TRACE_END(2, (unsigned long long)(uintptr_t)pooled)
+}
+
+
+// =============================================================================================
+// Pair form of the all-MFMA trunk (trunk_variant 7): ONE 8-wave workgroup per CU walks PAIRS of boards, every phase of the
+// algorithm above running for both boards of the pair before the next barrier.
+//   * the weight fragments of a layer (64 KB per workgroup from L2) are fetched once per PAIR, the barriers are paid once per
+//     pair (four per pair instead of four per board), and a wave has two boards' independent work between two barriers;
+//   * one workgroup of <= 256-register waves per CU: two waves per SIMD.
+// Timing-only ablations of the one-board form (tools/ab_trunk.py) put its matrix instructions at 20 % of its time, its barriers
+// at 16 %, everything else (weight / bias fragment traffic, splits, epilogues, setup) above 50 %: this form halves the first
+// two fixed costs per board.  Same arithmetic per board, same results.
+// LDS: 2 x (planes 41.5 KB + adjacency fragments 10 KB + G' rows 2.6 KB) + scratch = 113 KB.
+// =============================================================================================
+struct alignas(16) PairBoardSmem {
+    alignas(16) unsigned char P[2][PPLANE];            // fp16 hi / lo planes of this board's activation image
+    alignas(16) unsigned int AF[AF_BLOCKS][64][4];     // its adjacency fragments
+    alignas(16) unsigned short G16[81][16];            // its layer-1 input rows
+};
+struct alignas(16) TrunkPairSmem {
+    PairBoardSmem bd[2];
+    alignas(16) float Y[8][96];
+    alignas(16) unsigned short degv[8][2][32];
+};
+static_assert(sizeof(TrunkPairSmem) <= 160 * 1024, "one pair workgroup per CU");
+
+__global__ __launch_bounds__(512, 2) void gcn_trunk_pairs_kernel(const void* __restrict__ states, int fmt, int B, const float* __restrict__ pk,
+                                                                 float* __restrict__ pooled, const uint8_t* __restrict__ active,
+                                                                 int32_t* __restrict__ saturated) {
+    AQG_TRACE_BEGIN
+    constexpr int JT = 1, NWV = 8;
+    __shared__ TrunkPairSmem sm;
+    const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int wave = wave0;
+    const int npairs = (B + 1) >> 1;
+    int p = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(states), 0, B * (fmt == 0 ? 72 : 24), 0x00020000);
+    auto fetch_record = [&](int bb, uint32_t& r0, uint32_t& r1) {
+        const int ln = fresh_lane();
+        if (fmt == 0) {
+            r0 = __builtin_amdgcn_raw_buffer_load_b8(rst, 4 + ln, bb * 72, 0);
+            r1 = __builtin_amdgcn_raw_buffer_load_b32(rst, 0, bb * 72, 0);
+        } else {
+            r0 = __builtin_amdgcn_raw_buffer_load_b32(rst, (ln < 5 ? ln : 4) * 4, bb * 24, 0);
+        }
+    };
+    // a board of a pair is live when it exists and is not masked out (workgroup-uniform); a pair with no live board is skipped
+    auto live_of = [&](int b) -> bool { return b < B && !(active && !active[b]); };
+    auto next_pair = [&](int q0) -> int { while (q0 < npairs && !live_of(2 * q0) && !live_of(2 * q0 + 1)) q0 += gridDim.x; return q0; };
+    uint32_t rec0[2] = {0u, 0u}, rec1[2] = {0u, 0u};
+    // the first pair's records are requested before its `active` flags are known (two loads in flight together)
+    if (p < npairs) {
+        fetch_record(min(2 * p, B - 1), rec0[0], rec1[0]);
+        fetch_record(min(2 * p + 1, B - 1), rec0[1], rec1[1]);
+        const int p1 = next_pair(p);
+        if (p1 != p) {
+            p = p1;
+            if (p < npairs) { fetch_record(min(2 * p, B - 1), rec0[0], rec1[0]); fetch_record(min(2 * p + 1, B - 1), rec0[1], rec1[1]); }
+        }
+    }
+    // once per workgroup: the k-slots 6, 7 of the hi and lo halves of every G' row, which no board ever writes
+    for (int i = (int)threadIdx.x; i < 2 * 81 * 2; i += 512)
+        *reinterpret_cast<unsigned int*>(&sm.bd[i / 162].G16[0][0] + 16 * ((i % 162) >> 1) + 6 + 8 * (i & 1)) = 0u;
+    u32x4 Bf[2][JT][4];
+    const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pooled, 0, B * (HID * 4), 0x00020000);
+
+    while (p < npairs) {
+        wave = wave0;
+        asm volatile("" : "+s"(wave));
+        const int lane = fresh_lane(), c = lane & 15, q = lane >> 4;
+        const bool live0 = live_of(2 * p), live1 = live_of(2 * p + 1);      // workgroup-uniform
+        u32x4 w1f[JT];
+#pragma unroll
+        for (int j = 0; j < JT; ++j) w1f[j] = load_frag16(rs, lane * 16, (int)(PackedLayout::WH1 * sizeof(float)) + (wave * JT + j) * (64 * 16));
+        __builtin_amdgcn_sched_barrier(0);
+        int toff[2][3];
+        uint64_t hw[2], vw[2];
+        uint32_t hd[2];
+        f32x4 out[2][6][JT];
+        u32x4 zh[2][JT][3], zl[2][JT][3];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            trunk_decode(fmt, rec0[d], rec1[d], hw[d], vw[d], hd[d]);
+            trunk_bias_offsets(hw[d], vw[d], c, q, toff[d]);
+            request_bias<JT>(out[d], rs, 0, toff[d], wave);                // lands under the input build + barrier
+        }
+        if (live0) trunk_build_inputs<NWV>(sm.bd[0].G16, sm.bd[0].AF, sm.Y[wave], sm.degv[wave], wave, hw[0], vw[0], hd[0], 1);
+        if (live1) trunk_build_inputs<NWV>(sm.bd[1].G16, sm.bd[1].AF, sm.Y[wave], sm.degv[wave], wave, hw[1], vw[1], hd[1], 1);
+        const int pn = next_pair(p + gridDim.x);
+        __syncthreads();                      // both boards' G' rows are complete; the previous pair is done
+        // ---- layer 1
+        if (live0) layer1_store<JT>(sm.bd[0], sm.bd[0].G16, w1f, out[0], wave, lane, saturated);
+        if (live1) layer1_store<JT>(sm.bd[1], sm.bd[1].G16, w1f, out[1], wave, lane, saturated);
+        __builtin_amdgcn_sched_barrier(0);
+        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights, once for the pair
+        __builtin_amdgcn_sched_barrier(0);
+        if (live0) trunk_build_inputs<NWV>(sm.bd[0].G16, sm.bd[0].AF, sm.Y[wave], sm.degv[wave], wave, hw[0], vw[0], hd[0], 2);
+        if (live1) trunk_build_inputs<NWV>(sm.bd[1].G16, sm.bd[1].AF, sm.Y[wave], sm.degv[wave], wave, hw[1], vw[1], hd[1], 2);
+        __syncthreads();
+        // ---- layer 2
+        if (live0) request_bias<JT>(out[0], rs, 1, toff[0], wave);
+        if (live1) request_bias<JT>(out[1], rs, 1, toff[1], wave);
+        if (live0) linear_split<JT>(sm.bd[0], Bf, lane, zh[0], zl[0]);
+        if (live1) linear_split<JT>(sm.bd[1], Bf, lane, zh[1], zl[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH3, wave, lane);             // lands under the barrier + aggregation
+        uint32_t nrec0[2] = {0u, 0u}, nrec1[2] = {0u, 0u};
+        if (pn < npairs) { fetch_record(min(2 * pn, B - 1), nrec0[0], nrec1[0]); fetch_record(min(2 * pn + 1, B - 1), nrec0[1], nrec1[1]); }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                                    // every wave is done reading the planes
+        if (live0) aggregate_store<JT, false>(sm.bd[0], sm.bd[0].AF, zh[0], zl[0], out[0], wave, lane, toff[0], prs, 0, saturated);
+        if (live1) aggregate_store<JT, false>(sm.bd[1], sm.bd[1].AF, zh[1], zl[1], out[1], wave, lane, toff[1], prs, 0, saturated);
+        __syncthreads();
+        // ---- layer 3 + mean pool
+        if (live0) request_bias<JT>(out[0], rs, 2, toff[0], wave);
+        if (live1) request_bias<JT>(out[1], rs, 2, toff[1], wave);
+        if (live0) linear_split<JT>(sm.bd[0], Bf, lane, zh[0], zl[0]);
+        if (live1) linear_split<JT>(sm.bd[1], Bf, lane, zh[1], zl[1]);
+        if (live0) aggregate_store<JT, true>(sm.bd[0], sm.bd[0].AF, zh[0], zl[0], out[0], wave, lane, toff[0], prs, (2 * p) * (HID * 4), saturated);
+        if (live1) aggregate_store<JT, true>(sm.bd[1], sm.bd[1].AF, zh[1], zl[1], out[1], wave, lane, toff[1], prs, (2 * p + 1) * (HID * 4), saturated);
+        rec0[0] = nrec0[0]; rec0[1] = nrec0[1]; rec1[0] = nrec1[0]; rec1[1] = nrec1[1];
+        // (no barrier at the end of a pair: see the one-board form)
+        p = pn;
+    }
     AQG_TRACE_END(2, (unsigned long long)(uintptr_t)pooled)
 }
 
@@ -1891,6 +2030,11 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     } else if (variant == 1) {
         int grid = B < 512 ? B : 512;
         hipLaunchKernelGGL((gcn_trunk_boards_kernel<false, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
+    } else if (variant == 7) {
+        // pair form: one workgroup per CU, two boards per pass
+        int grid = (B + 1) / 2 < 256 ? (B + 1) / 2 : 256;
+        if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
+        hipLaunchKernelGGL(gcn_trunk_pairs_kernel, dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, saturated);
     } else if (variant == 4 || variant == 5) {
         // two 4-wave workgroups per CU (a wave owns 32 feature columns): half the LDS operand traffic of the 8-wave form
         int grid = B < 512 ? B : 512;

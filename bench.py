@@ -320,9 +320,23 @@ def main():
     _lib.set_option("trunk_variant", 3)
     fwd_ms = min(time_ms(fwd, 200, warmup=20) for _ in range(2))      # default variant, after the clocks have settled on this workload
 
-    step_leg = refill_leg = train_leg = legal_leg = None
+    step_leg = refill_leg = train_leg = legal_leg = graph_leg = None
     if world == 1 and not args.no_extra_legs:
         legal_leg = legal_mask_leg(dev, lib, _lib, synth_states)
+        # ---- the reference's literal operator forward(x, edge_index, batch) (pv_network_gnn.py:53-64) on the same boards given as
+        #      a PyG-style batch: gcn_norm / CSR built per call with torch ops, then the generic graph kernels (no board structure
+        #      assumed: any graph batch goes through here)
+        from tools.microbench import board_graph_batch
+        gx, gei, gb = board_graph_batch(boards)
+        with torch.no_grad():
+            pol_g, _ = model(gx, gei, gb)
+            gms = time_ms(lambda: model(gx, gei, gb), 10, warmup=2)
+            pol_b, _ = model.forward_states(boards)
+        graph_leg = {"workload": f"forward(x, edge_index, batch) on the {B} boards of gnn_forward as a graph batch ({gx.shape[0]} nodes, {gei.shape[1]} directed edges)",
+                     "boards_per_s": B / (gms * 1e-3), "ms": gms, "max_abs_diff_vs_board_path": float((pol_g - pol_b).abs().max()),
+                     "note": "the generic boundary path: host-side gcn_norm + CSR by torch ops on every call, plain f32 kernels (linear on the "
+                             "vector unit, CSR gather, pool), exact-f32 heads; it takes ANY graph batch. The engine never uses it: boards go "
+                             "through the fused trunk (gnn_forward)"}
         # (every MultiSetSelfPlay of a process runs on the same four streams, engine._SET_STREAMS: a second engine on four NEW streams
         # would share hardware queues with the first one's idle streams and ran 35 % slower)
         del eng
@@ -507,6 +521,8 @@ def main():
         legal_sample = legal_leg.pop("_sample", None) if legal_leg is not None else None
         if legal_leg is not None:
             out["legal_mask"] = legal_leg
+        if graph_leg is not None:
+            out["generic_graph_forward"] = graph_leg
         if step_leg is not None:
             out["step_kernel"] = step_leg
         if refill_leg is not None:

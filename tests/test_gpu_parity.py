@@ -153,7 +153,7 @@ def test_rules_and_mcts_on_7x7_vs_oracle(dev):
 
 
 # ------------------------------------------------------------------ K1/K2 GNN forward
-@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5, 6, 7])
 def test_gnn_forward_boards_vs_fp64_oracle(dev, variant):
     from alphaquoridorgnn_amd import _lib
     from oracle import gnn as og
@@ -230,7 +230,7 @@ def _walk_oracle(seed):
     return _WALK_ORACLE[seed]
 
 
-@pytest.mark.parametrize("variant,B", [(6, 4096), (6, 1000), (6, 2049), (5, 4096), (5, 1000), (5, 2049), (3, 8192), (1, 2049)])
+@pytest.mark.parametrize("variant,B", [(6, 4096), (6, 1000), (6, 2049), (5, 4096), (5, 1000), (5, 2049), (3, 8192), (1, 2049), (7, 4096), (7, 1001), (7, 2049), (7, 513)])
 def test_gnn_forward_many_boards_per_workgroup(dev, variant, B):
     """BASELINE configs[1] at its own size, and ragged sizes around the launch-size switches: with more than 512 boards a
     workgroup of the persistent trunk walks SEVERAL boards (next-record prefetch, LDS reuse between boards, the conditional end
@@ -266,7 +266,7 @@ def test_gnn_forward_many_boards_per_workgroup(dev, variant, B):
         _lib.set_option("trunk_variant", 3)
 
 
-@pytest.mark.parametrize("variant", [6, 5, 1])
+@pytest.mark.parametrize("variant", [6, 5, 1, 7])
 def test_engine_masked_trunk_launch(dev, variant):
     """The trunk as the ENGINE launches it: 24-byte packed leaf states (fmt 1) + the leaf_flag mask.  2,048 roots of which 35 %
     are terminal (enemy on its goal row: game_logic.py:43-46, never evaluated, pv_mcts.py:35-42), one simulation: the rows of

@@ -46,6 +46,37 @@ def synth_states(B, seed=0, p_wall=0.3, dev="cuda"):
     return pool[idx].contiguous()
 
 
+def board_graph_batch(states72):
+    """The boards of `states72` (uint8 [B,72], 9x9, device) as the arguments of the reference's literal operator
+    forward(x, edge_index, batch) (pv_network_gnn.py:53): node features pv_network_cnn.py:88-114 as x [B*81, 6], the wall-cut
+    4-neighbour grid (game_logic.py:145-167) as a directed edge list in both directions, batch [B*81].  Torch ops on the device."""
+    dev = states72.device
+    B = states72.shape[0]
+    N, S, V = 9, 8, 81
+    r = states72.long()
+    W = r[:, 4:68].view(B, S, S)
+    Hh = torch.zeros((B, S, N + 1), dtype=torch.bool, device=dev); Hh[:, :, 1:N] = W == 1
+    Vv = torch.zeros((B, N + 1, S), dtype=torch.bool, device=dev); Vv[:, 1:N, :] = W == 2
+    down = ~(Hh[:, :, 1:] | Hh[:, :, :N])                        # [B, S, N]: open between rows x and x + 1 at column y
+    right = ~(Vv[:, 1:, :] | Vv[:, :N, :])                       # [B, N, S]: open between columns y and y + 1 at row x
+    base = (torch.arange(B, device=dev) * V).view(B, 1, 1)
+    td = (torch.arange(S, device=dev).view(S, 1) * N + torch.arange(N, device=dev).view(1, N)).view(1, S, N) + base
+    tr = (torch.arange(N, device=dev).view(N, 1) * N + torch.arange(S, device=dev).view(1, S)).view(1, N, S) + base
+    a, b = td[down], tr[right]
+    src = torch.cat([a, a + N, b, b + 1]); dst = torch.cat([a + N, a, b + 1, b])
+    x = torch.zeros((B, V, 6), dtype=torch.float32, device=dev)
+    rows = torch.arange(B, device=dev)
+    x[rows, r[:, 0], 0] = 1.0
+    x[:, :, 1] = r[:, 1].float().unsqueeze(1)
+    x[rows, r[:, 2], 2] = 1.0
+    x[:, :, 3] = r[:, 3].float().unsqueeze(1)
+    tw = N * (torch.arange(S * S, device=dev) // S) + torch.arange(S * S, device=dev) % S
+    x[:, tw, 4] = (r[:, 4:68] == 1).float()
+    x[:, tw, 5] = (r[:, 4:68] == 2).float()
+    batch = torch.arange(B, device=dev).repeat_interleave(V)
+    return x.view(B * V, 6), torch.stack([src, dst]), batch
+
+
 def time_ms(fn, iters, warmup=5):
     for _ in range(warmup):
         fn()
