@@ -51,7 +51,7 @@ SPLIT_TERMS = 3                                                      # hi*hi + h
 TRUNK_MFMA_PER_BOARD = 4 * (12 + 2 * 144 + 3 * 40)                   # 16x16x32 fp16 MFMAs issued per board (incl. aggregation, padding)
 PEAK_HBM = 8.0e12
 # Compulsory global traffic of the default trunk per board: the 72-byte record (24 inside the engine) in, the 512-byte pooled
-# row out; the weight fragments are served by the L2 (hit rate 97.6-99.5 %, profiles/r02_pmc_l2_summary.csv).  PMC counters
+# row out; the weight fragments are served by the L2 (hit rate 97.5-99.5 %, profiles/r03_pmc_summary.csv).  PMC counters
 # cannot be collected from inside this process; what a rocprofv3 pass of THIS round measured is in profiles/r03_pmc_summary.csv
 # and quoted in DESIGN.md section 5 -- `roofline.traffic` stays null in the line rather than carrying a constant.
 TRUNK_COMPULSORY_BYTES_PER_BOARD = 72 + 512
@@ -366,10 +366,10 @@ def main():
             step_leg["waves_per_simd"][str(G)] = G / 1024.0
             del e1
         step_leg["note"] = ("HIP event pairs around every step launch of plies 24-31 of GNN-evaluated games (the pair also brackets the "
-                            "dispatch gap, ~3 us: rocprofv3 on the bench command gives 14.4 us at 512 games, profiles/r02_bench_kernel_stats_default_4sets.csv); one "
+                            "dispatch gap, ~3 us: rocprofv3 on the bench command gives 14.8 us at 512 games, profiles/r03_bench_kernel_stats_default_4sets.csv); one "
                             "wavefront per game; per simulation ONE round of dependent loads (root record + root children + the previous "
                             "leaf's policy, everything else patched in registers) plus one per tree level below the root; no bandwidth or "
-                            "FLOP roof applies (PMC: profiles/r02_pmc_summary.csv) -- the figure of merit is us per launch, which the "
+                            "FLOP roof applies (PMC: profiles/r03_pmc_summary.csv) -- the figure of merit is us per launch, which the "
                             "chain step -> trunk -> heads pays once per simulation")
         # ---- slot refill: the same 2048 slots, 3 x 2048 games; a finished game's slot takes the next game
         torch.cuda.empty_cache()
