@@ -1284,7 +1284,15 @@ __device__ __forceinline__ void trunk_bias_offsets(uint64_t hw, uint64_t vw, int
 
 // (hipcc's second launch-bound argument is waves per SIMD: workgroups per CU x waves per workgroup / 4 SIMDs)
 template <int JT, int WGS_PER_CU, bool FUSE = false>
-__global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trunk_boards_mm_kernel(const void* __restrict__ states, int fmt, int B,
+#ifdef AQG_TRUNK96
+// Experiment build: the 8-wave form capped at 96 vector registers (the compiler only honours a waves-per-SIMD request beyond what
+// the kernel's LDS allows when it cannot see the LDS size, hence dynamic LDS here): four trunk waves then leave 128 registers of a
+// SIMD free and an MCTS step wave (112) fits beside them -- a step workgroup no longer displaces a trunk workgroup (section K4).
+#define AQG_TRUNK_BOUNDS __attribute__((amdgpu_flat_work_group_size(64 * (8 / JT), 64 * (8 / JT)), amdgpu_waves_per_eu(JT == 1 ? 5 : 2, JT == 1 ? 5 : 2)))
+#else
+#define AQG_TRUNK_BOUNDS __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT))
+#endif
+__global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restrict__ states, int fmt, int B,
                                                                                         const float* __restrict__ pk,
                                                                                         float* __restrict__ pooled,
                                                                                         const uint8_t* __restrict__ active, int phase_delay,
@@ -1298,7 +1306,12 @@ __global__ __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT)) void gcn_trun
     constexpr int N = 9, V = 81, S = 8;
     constexpr int NWV = 8 / JT;
     constexpr int NSLOT = NWV == 4 ? 3 : 2;
+#ifdef AQG_TRUNK96
+    extern __shared__ __align__(16) unsigned char aqg_dyn_smem[];
+    TrunkSmemM<NWV>& sm = *reinterpret_cast<TrunkSmemM<NWV>*>(aqg_dyn_smem);
+#else
     __shared__ TrunkSmemM<NWV> sm;
+#endif
     // The two workgroups resident on a CU run identical phase sequences; a start offset for the second-resident ones
     // (phase_delay x 64 cycles) keeps one on the matrix pipe while the other does vector work.
     const int prio_mode = phase_delay >> 16;     // static wave priorities (aqg_set_option("trunk_prio"); chosen by launch size on the host)
@@ -2012,6 +2025,11 @@ int profile_collect(double* total_ms, long long* launches, long long* boards, in
     return 0;
 }
 
+#ifdef AQG_TRUNK96
+#define AQG_TRUNK_DYN(nwv) sizeof(TrunkSmemM<nwv>)
+#else
+#define AQG_TRUNK_DYN(nwv) 0
+#endif
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
                               int flags, int32_t* saturated, hipStream_t st) {
@@ -2039,7 +2057,7 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
         // two 4-wave workgroups per CU (a wave owns 32 feature columns): half the LDS operand traffic of the 8-wave form
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),
+        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), AQG_TRUNK_DYN(4), st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),
                            0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, saturated);
     } else {
         // two 8-wave workgroups per CU (a wave owns 16 feature columns): shortest latency per board AND, with four waves per
@@ -2048,11 +2066,11 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
         const bool want_heads = logits || policy || value_pre || value;
         if (want_heads && g_fuse_heads && B <= FUSE_HEADS_MAX && N * N + 2 * (N - 1) * (N - 1) <= APAD) {
-            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2, true>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, 0,
+            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2, true>), dim3(grid), dim3(512), AQG_TRUNK_DYN(8), st, states, fmt, B, packed, pooled, active, 0,
                                N * N + 2 * (N - 1) * (N - 1), logits, policy, value_pre, value, saturated);
             fused = true;
         } else {
-            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),
+            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), AQG_TRUNK_DYN(8), st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),
                                0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, saturated);
         }
     }
