@@ -1303,9 +1303,7 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
                                                                                         int32_t* __restrict__ saturated = nullptr) {
     static_assert(!FUSE || JT == 1, "the fused heads are written for the 512-thread form");
     AQG_TRACE_BEGIN
-    constexpr int N = 9, V = 81, S = 8;
     constexpr int NWV = 8 / JT;
-    constexpr int NSLOT = NWV == 4 ? 3 : 2;
 #ifdef AQG_TRUNK96
     extern __shared__ __align__(16) unsigned char aqg_dyn_smem[];
     TrunkSmemM<NWV>& sm = *reinterpret_cast<TrunkSmemM<NWV>*>(aqg_dyn_smem);

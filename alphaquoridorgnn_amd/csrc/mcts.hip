@@ -989,19 +989,24 @@ struct SimGraph {
     aqg_engine e;
     int opts[8];
     hipGraphExec_t exec;
+    hipEvent_t last;          // recorded behind every replay: eviction waits for THIS graph's last replay, not for the device
 };
 static std::vector<SimGraph> g_sim_graphs;
+constexpr size_t SIM_GRAPH_CACHE = 64;   // engines x game sets that can alternate without re-capturing (4 sets per engine: 16 engines)
+
+static int replay(SimGraph& g, hipStream_t st) {
+    if (hipGraphLaunch(g.exec, st) != hipSuccess) return fail("hipGraphLaunch");
+    if (hipEventRecord(g.last, st) != hipSuccess) return fail("hipEventRecord");
+    return 0;
+}
 
 template <int N>
 static int run_sims(const aqg_engine& e, hipStream_t st) {
     if (!g_use_graph || g_profile_trunk || st == nullptr || e.sims < 4) return enqueue_sims<N>(e, st);
     // every option a captured launch bakes in is part of the key: a changed option must never replay a stale graph
     const int opts[8] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth, g_fuse_heads | ((g_trunk_prio & 0xff) << 8) | (g_step_waves << 16) | (g_step_prio << 24) | (g_heads_prio << 28)};
-    for (const SimGraph& g : g_sim_graphs)
-        if (!memcmp(&g.e, &e, sizeof(aqg_engine)) && !memcmp(g.opts, opts, sizeof(opts))) {
-            if (hipGraphLaunch(g.exec, st) != hipSuccess) return fail("hipGraphLaunch");
-            return 0;
-        }
+    for (SimGraph& g : g_sim_graphs)
+        if (!memcmp(&g.e, &e, sizeof(aqg_engine)) && !memcmp(g.opts, opts, sizeof(opts))) return replay(g, st);
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         return enqueue_sims<N>(e, st);                       // stream not capturable: plain launches
@@ -1017,14 +1022,16 @@ static int run_sims(const aqg_engine& e, hipStream_t st) {
     const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) return fail("hipGraphInstantiate");
-    if (g_sim_graphs.size() >= 16) {                         // small FIFO cache: engines come and go
-        (void)hipDeviceSynchronize();                        // the evicted exec may still be replaying on another stream
-        (void)hipGraphExecDestroy(g_sim_graphs.front().exec);
+    if (hipEventCreateWithFlags(&g.last, hipEventDisableTiming) != hipSuccess) { (void)hipGraphExecDestroy(g.exec); return fail("hipEventCreate"); }
+    if (g_sim_graphs.size() >= SIM_GRAPH_CACHE) {            // FIFO: engines come and go
+        SimGraph& old = g_sim_graphs.front();
+        (void)hipEventSynchronize(old.last);                 // its last replay may still be running on ANOTHER stream: wait for that
+        (void)hipGraphExecDestroy(old.exec);                 // replay only -- the other game sets' streams keep running
+        (void)hipEventDestroy(old.last);
         g_sim_graphs.erase(g_sim_graphs.begin());
     }
     g_sim_graphs.push_back(g);
-    if (hipGraphLaunch(g.exec, st) != hipSuccess) return fail("hipGraphLaunch");
-    return 0;
+    return replay(g_sim_graphs.back(), st);
 }
 
 template <int N>

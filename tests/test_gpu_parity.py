@@ -1361,3 +1361,33 @@ def test_bench_two_ranks_on_one_gpu(dev, tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "games/s" and d["steps"] == 1
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 128) < 1e-6          # 2 ranks x 64 games, all finished
     assert d["positions_gathered_per_step"] > 128 and d["roofline"]["launches"] > 0
+
+
+def test_graph_cache_eviction_keeps_results(dev):
+    """A move's 3 x sims + 2 launches are replayed from a captured hipGraph, cached per engine (csrc/mcts.hip run_sims: 64 entries,
+    FIFO).  More engines than entries alternate on a side stream, so execs are evicted (waiting for THEIR last replay only) and
+    re-captured: every engine's games must still equal the same engine played with plain launches."""
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay
+    side = torch.cuda.Stream(device=dev)
+    n = 70
+
+    def run(use_graph):
+        _lib.set_option("use_graph", use_graph)
+        hist = []
+        with torch.cuda.stream(side):
+            engines = [BatchedSelfPlay(None, num_games=2, sims=6, evaluator="fake", fake_bias=3, seed=100 + i) for i in range(n)]
+            for rnd in range(3):                       # round-robin: engine 0's graph is long evicted when its turn comes again
+                for e in engines:
+                    e.move()
+            side.synchronize()
+            for e in engines:
+                hist.append(tuple(x.cpu() for x in (e.t["hist_action"][:, :3], e.t["root_state"])))
+        return hist
+
+    try:
+        a, b = run(1), run(0)
+    finally:
+        _lib.set_option("use_graph", 1)
+    for (ha, ra), (hb, rb) in zip(a, b):
+        assert torch.equal(ha, hb) and torch.equal(ra, rb)
