@@ -1391,3 +1391,30 @@ def test_graph_cache_eviction_keeps_results(dev):
         _lib.set_option("use_graph", 1)
     for (ha, ra), (hb, rb) in zip(a, b):
         assert torch.equal(ha, hb) and torch.equal(ra, rb)
+
+
+def test_generation_replays_on_exact_kernels_after_range_guard(dev):
+    """The engine side of the fp16-range guard: when the split kernels report a value outside fp16 range during a generation
+    (counters[5]; forced here, since positions reached by play look like the calibration boards), play_generation switches the
+    engine and the model to the exact f32-input kernels and plays the generation again from the start -- also with several game
+    sets -- instead of keeping moves that were searched with clamped evaluations."""
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay, MultiSetSelfPlay
+    model, _ = _model(5)
+    assert model.gnn_flags(dev) == 0
+    eng = BatchedSelfPlay(model, num_games=6, sims=6, seed=3)
+    for _ in range(3):
+        eng.move()
+    eng.t["counters"][5] = 1                      # what a saturating launch would have done
+    c = eng.play_generation()
+    assert eng.e.gnn_flags == _lib.GNN_EXACT_F32 and model.gnn_flags(dev) == _lib.GNN_EXACT_F32
+    assert c["finished"] == 6 and c["active"] == 0 and c["gnn_saturated"] == 0
+    st, vis, z = eng.history_tensors()
+    assert st.shape[0] == vis.shape[0] == z.shape[0] and (vis.sum(1) == 5).all()
+    # several sets: one set's counter is enough
+    model2, _ = _model(5)
+    ms = MultiSetSelfPlay(model2, num_games=8, sims=6, num_sets=2, seed=4)
+    ms.move()
+    ms.sets[1].t["counters"][5] = 1
+    c = ms.play_generation()
+    assert all(e.e.gnn_flags == _lib.GNN_EXACT_F32 for e in ms.sets) and c["finished"] == 8 and c["gnn_saturated"] == 0
