@@ -501,6 +501,10 @@ def main():
                                          "PMC-measured bytes of this round: profiles/r03_pmc_summary.csv (collected by a separate rocprofv3 pass, "
                                          "quoted in DESIGN.md section 5); the algorithmic layer-granular figure is 169,760 B/board (hbm_frac_survey_formula)",
                          "frac_vs_dense_f16_peak": achieved / PEAK_F16_MFMA,
+                         "mfma_busy_pmc": {"boards_per_launch_65536": 0.49, "boards_per_launch_480": 0.41,
+                                           "source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) from the separate rocprofv3 --pmc passes of "
+                                                     "this round, profiles/r03_pmc_summary.csv (480: against the un-instrumented launch time); a recorded "
+                                                     "measurement, not taken in this run"},
                          "launches": trunk_launches, "avg_launch_us": trunk_ms / max(trunk_launches, 1) * 1e3,
                          "boards_per_launch_avg": trunk_boards / max(trunk_launches, 1),
                          "launches_sampled": "every trunk launch of one game set's move on plies 27/83 of each timed generation; that set runs alone on the GPU with plain launches for that move, all other moves replay captured hipGraphs with the sets overlapping",
