@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQG_LIB_PATH", os.path.join(_HERE, "libaqgnn_hip.so"))  # override: diagnostic builds only
 MAX_LEGAL = 136
 GNN_EXACT_F32 = 1        # AQG_GNN_EXACT_F32 (include/aqgnn.h)
-ABI_VERSION = 7
+ABI_VERSION = 8
 TRAIN_PART_FLOATS = 2 * 128 * 128 + 128 * 6 + 3 * 128    # AQG_TRAIN_PART_FLOATS, per position of the batch
 
 _c = ctypes
@@ -74,6 +74,7 @@ SIGNATURES = {
     "aqg_engine_root_visits": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp, _vp, _vp]),
     "aqg_gcn_train_step": (_c.c_int, [_c.POINTER(TrainStruct), _vp, _vp, _vp, _c.c_int, _vp]),
     "aqg_gcn_train_steps": (_c.c_int, [_c.POINTER(TrainStruct), _vp, _vp, _vp, _vp, _c.c_longlong, _vp, _vp]),
+    "aqg_gcn_train_fallbacks": (_c.c_longlong, [_c.c_int]),
     "aqg_host_legal_actions": (_c.c_int, [_c.c_int, _vp, _vp]),
     "aqg_host_next": (_c.c_int, [_c.c_int, _vp, _c.c_int, _vp]),
     "aqg_host_shortest_path": (_c.c_int, [_c.c_int, _vp]),

@@ -49,6 +49,7 @@ int engine_move(const aqg_engine& e, const double* uniforms, hipStream_t st);
 int engine_search(const aqg_engine& e, const uint8_t* roots72, hipStream_t st);
 int engine_root_visits(const aqg_engine& e, int32_t* visits, uint8_t* actions, int32_t* count, hipStream_t st);
 int train_step(const aqg_train& t, const uint8_t* states72, const float* pi, const float* z, int mode, hipStream_t st);
+long long train_fallbacks(int reset);
 int train_steps(const aqg_train& t, const uint8_t* states72, const float* pi, const float* z, const int64_t* order, long long positions,
                 float* loss_sums, hipStream_t st);
 }  // namespace aqg
@@ -72,7 +73,7 @@ int aqg_set_option(const char* name, int value) {
     if (name && !strcmp(name, "step_variant")) { g_step_variant = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "step_fast_depth")) { if (value < 0 || value > 61) return fail("step_fast_depth must be 0..61"); g_step_fast_depth = value; return 0; }
     if (name && !strcmp(name, "fuse_heads")) { g_fuse_heads = value ? 1 : 0; return 0; }
-    if (name && !strcmp(name, "train_fused")) { g_train_fused = value ? 1 : 0; return 0; }
+    if (name && !strcmp(name, "train_fused")) { if (value < 0 || value > 3) return fail("train_fused: 0..3"); g_train_fused = value; return 0; }
     if (name && !strcmp(name, "use_graph")) { g_use_graph = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "profile_trunk")) { g_profile_trunk = (value == 1 || value == 2) ? value : 0; return 0; }   // 1 = trunk launches, 2 = step launches
     return fail("unknown option", name ? name : "(null)");
@@ -193,6 +194,7 @@ int aqg_gcn_train_step(const aqg_train* t, const uint8_t* states72, const float*
     if (mode >= 1 && t->step < 1) return fail("aqg_gcn_train_step: step must be >= 1");
     return train_step(*t, states72, pi_target, z_target, mode, (hipStream_t)stream);
 }
+long long aqg_gcn_train_fallbacks(int reset) { return train_fallbacks(reset); }
 int aqg_gcn_train_steps(const aqg_train* t, const uint8_t* states72, const float* pi_target, const float* z_target, const int64_t* order,
                         long long positions, float* loss_sums, void* stream) {
     if (!t || !states72 || !pi_target || !z_target || positions < 0 || positions > 0x7fffffffLL) return fail("aqg_gcn_train_steps: bad argument");

@@ -31,6 +31,7 @@
 // A board's 81 node rows never leave its workgroup (the aggregation needs all of them).  No atomics anywhere: results are
 // run-to-run identical.
 #include "aqg_common.hpp"
+#include "split_mfma.hpp"
 #include "../../include/aqgnn.h"
 
 namespace aqg {
@@ -56,6 +57,12 @@ __device__ unsigned long long g_train_stamp[10][16];
 #define TS(k, i)
 #endif
 
+#ifdef AQG_TRAIN_DEBUG      // developer build only (tools/train_debug.py): dense dumps of intermediate gradients, [slot][b][96][128]
+__device__ float* g_train_dbg = nullptr;
+#define DBG_PUT(slot, B_, b_, n_, col_, v_) { if (g_train_dbg) g_train_dbg[(((size_t)(slot) * (B_) + (b_)) * 96 + (n_)) * 128 + (col_)] = (v_); }
+#else
+#define DBG_PUT(slot, B_, b_, n_, col_, v_)
+#endif
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -389,10 +396,31 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
-struct HeadsSmem { float gs[TH], hs[TH], dhs[TH], dl[256], red[2][8][2], part[4 * TH]; };
-// One position's heads, losses and head gradients by a workgroup of NW wavefronts (the first four do the work; all take part
-// in the barriers).  `sm.gs` = the pooled features if g == nullptr (the fused kernel has them in LDS already); on return
-// sm.part[0..127] + sm.part[128..255] = dg, also stored to dg_out if that is not null.
+struct HeadsSmem {
+    float gs[TH], hs[TH], dhs[TH], dl[256], red[2][8][2];
+    float dgv[TH];                       // d loss / d pooled features: the result the backward pass starts from
+    alignas(16) float part[32][TH];      // per (wave, row group): partial sums over that group's weight rows
+};
+__device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b) { return fmaf(a[3], b[3], fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0]))); }
+__device__ __forceinline__ float row16_total(float x) {          // sum over the 16 lanes of a DPP row, in every lane of the row
+    x += dpp_f<0x128, 0xf>(0.f, x);    // row_ror:8
+    x += dpp_f<0x124, 0xf>(0.f, x);    // row_ror:4
+    x += dpp_f<0x122, 0xf>(0.f, x);    // row_ror:2
+    x += dpp_f<0x121, 0xf>(0.f, x);    // row_ror:1
+    return x;
+}
+// One position's heads, losses and head gradients by a workgroup of NW wavefronts (all of them load and multiply; the softmax /
+// loss reductions run on the first four).  `sm.gs` = the pooled features if g == nullptr (the fused kernels have them in LDS
+// already); on return sm.dgv = dg, also stored to dg_out if that is not null.
+//
+// Weight access.  Every matrix is read ONCE, by 16-byte loads, into registers that serve its forward product AND its transposed
+// product on the way back: a quarter wave (16 lanes = one DPP row) owns a weight row, lane l of it holds columns 4 l .. 4 l + 3 (and
+// 64 + 4 l .. for the 128-wide first layers), so
+//   forward    y[row]  = sum_k W[row][k] x[k]     = 4 or 8 FMAs per lane + four DPP row rotations
+//   backward   dx[k]  += dy[row] W[row][k]          = FMAs into the lane's own columns, no reduction until the rows of the 4 NW
+//                                                     quarter waves are added up through LDS in a fixed order.
+// (Before: one row per wave instruction with a 64-lane reduction per row, policy_head.2 and both first layers read twice, the
+//  second time with 4-byte strided loads -- 180 vector-memory instructions and ~100 weight registers per lane; now 15 and 60.)
 template <int NW>
 __device__ __forceinline__ void heads_board(HeadsSmem& sm, int b, const float* __restrict__ g, const HeadParams& Pm,
                                             const float* __restrict__ pi_all, const float* __restrict__ z_all,
@@ -402,8 +430,8 @@ __device__ __forceinline__ void heads_board(HeadsSmem& sm, int b, const float* _
                                             float* __restrict__ loss, float* __restrict__ dhp, float* __restrict__ dhv,
                                             float* __restrict__ dg) {
     float (&gs)[TH] = sm.gs; float (&hs)[TH] = sm.hs; float (&dhs)[TH] = sm.dhs; float (&dl)[256] = sm.dl;
-    float (&red)[2][8][2] = sm.red; float (&part)[4 * TH] = sm.part;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float (&red)[2][8][2] = sm.red;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, rg = lane >> 4, l = lane & 15;
     const bool worker = t < 256;
     const float *Wp1 = Pm.p[0], *bp1 = Pm.p[1], *Wp2 = Pm.p[2], *bp2 = Pm.p[3], *Wv1 = Pm.p[4], *bv1 = Pm.p[5], *Wv2 = Pm.p[6], *bv2 = Pm.p[7];
     const size_t rec = record_of(order, first, b);
@@ -420,45 +448,36 @@ __device__ __forceinline__ void heads_board(HeadsSmem& sm, int b, const float* _
     TS_DECL
     constexpr int HEADS_TS = NW == 4 ? 2 : 7;
     (void)HEADS_TS;
-    // Every weight this workgroup multiplies by is requested up front, and by COALESCED loads: a wave takes whole rows of the
-    // two first-layer matrices (512 B: two columns per lane) and of policy_head.2 (256 B: one column per lane) and reduces
-    // each row's products with a DPP wave sum.  (One thread per output row -- 64 different rows per load instruction -- spent
-    // 14 k cycles in the address unit before the first multiply.)
     const bool on = t < A;
-    constexpr int HROWS = TH / NW;                                  // hidden units per wave (rows w, w + NW, ...)
-    constexpr int LROWS = (256 + NW - 1) / NW;                      // logits per wave
-    float wh0[HROWS], wh1[HROWS], wl[LROWS];
+    constexpr int HG = TH / (4 * NW);                               // first-layer row groups per wave (4 rows each)
+    constexpr int LG = 64 / NW;                                     // policy_head.2 row groups per wave: 64 groups = 256 rows >= A
+    f32x4 w1a[HG], w1b[HG], w2[LG];
+    float hb[HG];
 #pragma unroll
-    for (int i = 0; i < HROWS; ++i) {
-        const int o = wave + NW * i;
-        const float* wr = (o < HH ? Wp1 + (size_t)o * TH : Wv1 + (size_t)(o - HH) * TH) + 2 * lane;
-        wh0[i] = wr[0]; wh1[i] = wr[1];
+    for (int i = 0; i < HG; ++i) {
+        const int o = 4 * (wave + NW * i) + rg;                     // hidden unit: 0..63 policy head, 64..127 value head
+        const float* wr = (o < HH ? Wp1 + (size_t)o * TH : Wv1 + (size_t)(o - HH) * TH) + 4 * l;
+        w1a[i] = ld4(wr); w1b[i] = ld4(wr + 64);
+        hb[i] = o < HH ? bp1[o] : bv1[o - HH];
     }
 #pragma unroll
-    for (int i = 0; i < LROWS; ++i) {
-        const int a = wave + NW * i;
-        wl[i] = a < A ? Wp2[(size_t)a * HH + lane] : 0.f;
+    for (int i = 0; i < LG; ++i) {
+        const int a = 4 * (wave + NW * i) + rg;
+        w2[i] = a < A ? ld4(Wp2 + (size_t)a * HH + 4 * l) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    constexpr int DROWS = 256 / NW;                                    // d loss / d policy hidden layer: the A terms dealt over the waves
-    const int per = (A + NW - 1) / NW, a0 = wave * per;
-    float wd[DROWS];
-#pragma unroll
-    for (int u = 0; u < DROWS; ++u) wd[u] = (u < per && a0 + u < A) ? Wp2[(size_t)(a0 + u) * HH + lane] : 0.f;
     const float tgt = on ? pi_all[rec * A + t] : 0.f;
     const float zt = z_all[rec];
     const float lb = on ? bp2[t] : 0.f, wv2 = Wv2[lane], bv = bv2[0];
-    const float hbias = lane < HROWS ? ((wave + NW * lane) < HH ? bp1[wave + NW * lane] : bv1[wave + NW * lane - HH]) : 0.f;
     if (g && t < TH) gs[t] = g[(size_t)b * TH + t];
     __syncthreads();
     TS(HEADS_TS, 0)
     {   // hidden layers: hs[0..63] policy, hs[64..127] value
-        const float g0 = gs[2 * lane], g1 = gs[2 * lane + 1];
+        const f32x4 g0 = ld4(gs + 4 * l), g1 = ld4(gs + 64 + 4 * l);
 #pragma unroll
-        for (int i = 0; i < HROWS; ++i) {
-            const int o = wave + NW * i;
-            float s = wave_sum(fmaf(wh0[i], g0, wh1[i] * g1));
-            s = fmaxf(s + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hbias), i)), 0.f);
-            if (lane == 0) {
+        for (int i = 0; i < HG; ++i) {
+            const int o = 4 * (wave + NW * i) + rg;
+            const float s = fmaxf(row16_total(dot4(w1a[i], g0) + dot4(w1b[i], g1)) + hb[i], 0.f);
+            if (l == 0) {
                 hs[o] = s;
                 (o < HH ? hp : hv)[(size_t)b * HH + (o & 63)] = s;
             }
@@ -467,20 +486,20 @@ __device__ __forceinline__ void heads_board(HeadsSmem& sm, int b, const float* _
     __syncthreads();
     TS(HEADS_TS, 1)
     {
-        const float h = hs[lane];
+        const f32x4 h4 = ld4(hs + 4 * l);
 #pragma unroll
-        for (int i = 0; i < LROWS; ++i) {
-            const int a = wave + NW * i;
-            const float s = wave_sum(wl[i] * h);
-            if (lane == 0 && a < A) dl[a] = s;                       // (dl is reused for d loss / d logits below)
+        for (int i = 0; i < LG; ++i) {
+            const int a = 4 * (wave + NW * i) + rg;
+            const float s = row16_total(dot4(w2[i], h4));
+            if (l == 0 && a < A) dl[a] = s;                          // (dl is reused for d loss / d logits below)
         }
     }
     __syncthreads();
-    const float l = on ? dl[t] + lb : -INFINITY;
+    const float lgt = on ? dl[t] + lb : -INFINITY;
     __syncthreads();                                                 // everybody holds its logit before dl is overwritten
     TS(HEADS_TS, 2)
-    const float m = block_max(l);
-    const float e = on ? expf(l - m) : 0.f;
+    const float m = block_max(lgt);
+    const float e = on ? expf(lgt - m) : 0.f;
     float se = e, tsum = tgt;
     block_sum2(se, tsum);
     const float p = e / se;                                      // first softmax (the network's own, pv_network_gnn.py:42)
@@ -492,7 +511,7 @@ __device__ __forceinline__ void heads_board(HeadsSmem& sm, int b, const float* _
     float lp = on ? -tgt * (p - logf(s2)) : 0.f, dot = dpol * p;
     block_sum2(lp, dot);
     const float dlogit = on ? p * (dpol - dot) : 0.f;            // back through the first softmax
-    if (worker) dl[t] = dlogit;
+    if (worker) dl[t] = dlogit;                                  // (zero for the rows A..255 of the padded row groups)
     if (on) {
         pol[(size_t)b * A + t] = p;
         lg[(size_t)b * A + t] = dlogit;
@@ -508,11 +527,11 @@ __device__ __forceinline__ void heads_board(HeadsSmem& sm, int b, const float* _
     }
     __syncthreads();
     TS(HEADS_TS, 3)
-    {
-        float s = 0.f;
+    {   // d loss / d policy hidden layer: this quarter wave's rows of policy_head.2, transposed product
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < DROWS; ++u) s = fmaf(dl[min(a0 + u, 255)], wd[u], s);
-        part[wave * HH + lane] = s;
+        for (int i = 0; i < LG; ++i) acc += dl[4 * (wave + NW * i) + rg] * w2[i];
+        st4(&sm.part[4 * wave + rg][4 * l], acc);
     }
     __syncthreads();
     TS(HEADS_TS, 4)
@@ -520,8 +539,9 @@ __device__ __forceinline__ void heads_board(HeadsSmem& sm, int b, const float* _
         const int j = t & 63;
         float s;
         if (t < HH) {
-            s = (part[j] + part[HH + j]) + (part[2 * HH + j] + part[3 * HH + j]);
-            if (NW == 8) s += (part[4 * HH + j] + part[5 * HH + j]) + (part[6 * HH + j] + part[7 * HH + j]);
+            s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4 * NW; ++r) s += sm.part[r][j];
         } else s = dvp * Wv2[j];
         if (!(hs[t] > 0.f)) s = 0.f;
         dhs[t] = s;
@@ -529,17 +549,26 @@ __device__ __forceinline__ void heads_board(HeadsSmem& sm, int b, const float* _
     }
     __syncthreads();
     TS(HEADS_TS, 5)
-    {   // dg = dhp W_p1 + dhv W_v1: threads 0..127 the policy part, 128..255 the value part
-        const int k = t & 127, hsel = (t >> 7) & 1;
-        const float* W = hsel ? Wv1 : Wp1;
-        float s = 0.f;
-#pragma unroll 16
-        for (int j = 0; j < HH; ++j) s = fmaf(dhs[hsel * HH + j], W[(size_t)j * TH + k], s);
-        if (worker) part[hsel * TH + k] = s;
+    {   // dg = dhp W_p1 + dhv W_v1: this quarter wave's rows of the two first layers, transposed product
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < HG; ++i) {
+            const float d = dhs[4 * (wave + NW * i) + rg];
+            a0 += d * w1a[i]; a1 += d * w1b[i];
+        }
+        st4(&sm.part[4 * wave + rg][4 * l], a0);
+        st4(&sm.part[4 * wave + rg][64 + 4 * l], a1);
     }
     __syncthreads();
     TS(HEADS_TS, 6)
-    if (dg && t < TH) dg[(size_t)b * TH + t] = part[t] + part[TH + t];
+    if (t < TH) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4 * NW; ++r) s += sm.part[r][t];
+        sm.dgv[t] = s;
+        if (dg) dg[(size_t)b * TH + t] = s;
+    }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void train_heads_kernel(const float* __restrict__ g, HeadParams Pm,
@@ -684,22 +713,26 @@ __global__ __launch_bounds__(256) void train_bwd_kernel(const uint8_t* __restric
 // weight gradient and as the ReLU mask of the next layer down).
 // ---------------------------------------------------------------------------------------------
 struct TrunkParams { const float* p[6]; };       // state_dict tensors 0..5
+// (the body is a device function over ONE raw LDS block so that the split-precision kernel below can fall back to it for a board
+//  whose values leave fp16 range without owning two sets of static LDS arrays; `hrows` = rows per board of the h1 / h2 buffers)
+constexpr int F32_BODY_SMEM = (int)(sizeof(float) * (2 * 96 * SA + 84 * SB + 4 * TH) + sizeof(BoardGraph));
 template <int N>
-__global__ __launch_bounds__(512) void train_board_kernel(const uint8_t* __restrict__ states72, const int64_t* __restrict__ order, int first,
-                                                          TrunkParams tp, HeadParams hpm, const float* __restrict__ pi_all,
-                                                          const float* __restrict__ z_all, int A, int B,
-                                                          float* __restrict__ h1, float* __restrict__ h2, float* __restrict__ g_out,
-                                                          float* __restrict__ hp, float* __restrict__ hv, float* __restrict__ lg,
-                                                          float* __restrict__ pol, float* __restrict__ vp, float* __restrict__ val,
-                                                          float* __restrict__ loss, float* __restrict__ dhp, float* __restrict__ dhv,
-                                                          float* __restrict__ part_dW3, float* __restrict__ part_dW2,
-                                                          float* __restrict__ part_dW1, float* __restrict__ part_db) {
+__device__ __forceinline__ void train_board_f32_body(unsigned char* __restrict__ smem, const uint8_t* __restrict__ states72,
+                                                     const int64_t* __restrict__ order, int first,
+                                                     const TrunkParams& tp, const HeadParams& hpm, const float* __restrict__ pi_all,
+                                                     const float* __restrict__ z_all, int A, int B, int hrows,
+                                                     float* __restrict__ h1, float* __restrict__ h2, float* __restrict__ g_out,
+                                                     float* __restrict__ hp, float* __restrict__ hv, float* __restrict__ lg,
+                                                     float* __restrict__ pol, float* __restrict__ vp, float* __restrict__ val,
+                                                     float* __restrict__ loss, float* __restrict__ dhp, float* __restrict__ dhv,
+                                                     float* __restrict__ part_dW3, float* __restrict__ part_dW2,
+                                                     float* __restrict__ part_dW1, float* __restrict__ part_db) {
     constexpr int V = N * N, RT = (V + 15) / 16, VK = (V + 3) / 4 * 4, NIT = (V + 15) / 16;
-    __shared__ float Hs[96 * SA];
-    __shared__ float Zs[96 * SA];
-    __shared__ float Hb[84 * SB];
-    __shared__ float cs[4 * TH];
-    __shared__ BoardGraph gr;
+    float* const Hs = reinterpret_cast<float*>(smem);
+    float* const Zs = Hs + 96 * SA;
+    float* const Hb = Zs + 96 * SA;
+    float* const cs = Hb + 84 * SB;
+    BoardGraph& gr = *reinterpret_cast<BoardGraph*>(cs + 4 * TH);
     HeadsSmem& hsm = *reinterpret_cast<HeadsSmem*>(Zs);
     static_assert(sizeof(HeadsSmem) <= sizeof(float) * 96 * SA && 16 * TH <= 84 * SB, "scratch aliases");
     const int b = blockIdx.x, t = threadIdx.x;
@@ -760,7 +793,7 @@ __global__ __launch_bounds__(512) void train_board_kernel(const uint8_t* __restr
             if (n < V) {
                 const f32x4 a = relu4(agg_row<SA>(Zs, gr, n, c4) + bv);
                 st4(Hs + n * SA + c4, a);
-                if (hglob) st4(hglob + ((size_t)b * V + n) * TH + c4, a);
+                if (hglob) st4(hglob + ((size_t)b * hrows + n) * TH + c4, a);
             }
         }
     };
@@ -831,7 +864,7 @@ __global__ __launch_bounds__(512) void train_board_kernel(const uint8_t* __restr
         // callers have passed a barrier since the last read of Zs / of Hs as an A operand / of Hb as a mask
         acc_to_Zs();
         cs[q * TH + col] = dbp;
-        if (hprev) hin.issue(hprev + (size_t)b * V * TH, t);
+        if (hprev) hin.issue(hprev + (size_t)b * hrows * TH, t);
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -861,7 +894,7 @@ __global__ __launch_bounds__(512) void train_board_kernel(const uint8_t* __restr
     };
     // layer 3: dH3 = dg / V on every node (global_mean_pool backward); the mask is H3, still in Hs
     {
-        const float v = (hsm.part[col] + hsm.part[TH + col]) / (float)V;
+        const float v = hsm.dgv[col] / (float)V;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{v, v, v, v};
         const float dbp = mask_and_bias_grad(Hs, SA);
@@ -877,7 +910,14 @@ __global__ __launch_bounds__(512) void train_board_kernel(const uint8_t* __restr
         mfma_rows_reg<RT>(acc, Hs, bw, r16, q);
         TS(8, 9)
         load_bfrag(bw, W2, TH, 1, col, q);
+#ifdef AQG_TRAIN_DEBUG
+        for (int rt = 0; rt < RT; ++rt) for (int i = 0; i < 4; ++i) if (16 * rt + 4 * q + i < V) DBG_PUT(1, B, b, 16 * rt + 4 * q + i, col, acc[rt][i])
+        for (int i = t; i < V * TH; i += 512) DBG_PUT(2, B, b, i / TH, i % TH, Hs[(i / TH) * SA + (i % TH)])
+#endif
         const float dbp = mask_and_bias_grad(Hb, SB);
+#ifdef AQG_TRAIN_DEBUG
+        for (int rt = 0; rt < RT; ++rt) for (int i = 0; i < 4; ++i) if (16 * rt + 4 * q + i < V) DBG_PUT(0, B, b, 16 * rt + 4 * q + i, col, acc[rt][i])
+#endif
         __syncthreads();                                             // dZ3 (Hs) and H2 (Hb) are dead
         finish_layer(dbp, h1, part_db + (size_t)B * TH);
         TS(8, 10)
@@ -906,6 +946,548 @@ __global__ __launch_bounds__(512) void train_board_kernel(const uint8_t* __restr
     }
     if (warm_sink == -1.2345678e-31f) part_db[0] = warm_sink;          // (keeps the warm-up loads alive; never taken)
 }
+template <int N>
+__global__ __launch_bounds__(512) void train_board_kernel(const uint8_t* __restrict__ states72, const int64_t* __restrict__ order, int first,
+                                                          TrunkParams tp, HeadParams hpm, const float* __restrict__ pi_all,
+                                                          const float* __restrict__ z_all, int A, int B, int hrows,
+                                                          float* __restrict__ h1, float* __restrict__ h2, float* __restrict__ g_out,
+                                                          float* __restrict__ hp, float* __restrict__ hv, float* __restrict__ lg,
+                                                          float* __restrict__ pol, float* __restrict__ vp, float* __restrict__ val,
+                                                          float* __restrict__ loss, float* __restrict__ dhp, float* __restrict__ dhv,
+                                                          float* __restrict__ part_dW3, float* __restrict__ part_dW2,
+                                                          float* __restrict__ part_dW1, float* __restrict__ part_db) {
+    __shared__ __align__(16) unsigned char smem[F32_BODY_SMEM];
+    train_board_f32_body<N>(smem, states72, order, first, tp, hpm, pi_all, z_all, A, B, hrows, h1, h2, g_out, hp, hv, lg, pol, vp, val, loss,
+                            dhp, dhv, part_dW3, part_dW2, part_dW1, part_db);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same step of ONE 9x9 position with every contraction on the 16-bit matrix pipe in split precision (split_mfma.hpp): the
+// default on the 9x9 board.  v_mfma_f32_16x16x32_f16 runs at 16x the rate of the f32-input MFMA the body above uses; with three
+// fp16 terms per f32 product the contractions cost a fifth, and the neighbourhood aggregation -- a VALU gather over LDS above,
+// 38 % of that kernel -- becomes 30 MFMAs on the board's banded A_hat (ten 32x16 blocks, f32 entries split hi / lo).
+//
+// Layouts.  Wave w owns feature columns 16 w .. 16 w + 15 everywhere.  A 16x16 accumulator tile has lane = column c (lane & 15)
+// and rows 4 q + r (q = lane >> 4) in its four registers; two consecutive row tiles of NODES are therefore an operand fragment of
+// any product contracted over the nodes (k-slot order of split_mfma.hpp), with no data movement:
+//   linear map      U = X W^T        A = fp16 planes of X in LDS [node][feature] (ds_read_b128), B = this wave's rows of W, split on
+//                                    the fly from the f32 master weights  ->  U: lane = feature, registers = nodes
+//   aggregation, T  V^T = U^T A_hat  A = U (registers), B = A_hat block  ->  lane = node, registers = 4 consecutive features:
+//                                    relu, split, 8-byte plane stores: the next linear map's A operand
+//   aggregation, R  V = A_hat U      A = A_hat block (the SAME fragment: A_hat is symmetric), B = U (registers)  ->  lane = feature,
+//                                    registers = nodes: an operand of the weight gradient dW = dZ^T H, which contracts over nodes
+//   weight gradient dW[all j][k in the wave's 16] = sum_n dZ[n][j] H[n][k]: B = the wave's OWN H fragments (form R of the forward
+//                                    pass, parked in memory lane-linearly and read back), A = the dZ fragments of all eight waves
+//                                    through 48 KB of LDS, lane-linear (form R of the backward pass)
+// so a layer costs 72 (linear) + 30 + 30 (both forms) MFMAs per wave going forward, and 72 (data gradient) + 60 + 72 (weight
+// gradient) going back; nothing is ever transposed.  ReLU masks are 24 bits per lane and layer, kept in registers.
+// Range: forward values are O(1); the backward pass is scaled per board by a power of two that puts max |dg| at 128..256 (the
+// gradients of a mean loss over 128 positions would otherwise sit in fp16's subnormals) and unscaled, exactly, at the stores of
+// the partial sums.  Every f32 value is range-checked before it is split; a board that meets |x| > 65504 anywhere is redone
+// by the exact-f32 body above in the same launch (counted in g_train_fallbacks) -- the reference's fp32 has no such cliff.
+// ---------------------------------------------------------------------------------------------
+struct alignas(16) SplitSmem {
+    alignas(16) unsigned char P[2][PPLANE];                 // fp16 hi / lo planes [node][feature]: H_l going forward, dZ_l going back
+    alignas(16) unsigned int AF[2][AF_BLOCKS][64][4];       // hi / lo fragments of the ten non-zero blocks of A_hat
+    alignas(16) unsigned int FR[8][3][2][64][4];            // [wave][k block][hi / lo]: dZ_l as A fragments of the weight gradient (the heads' scratch before)
+    alignas(16) unsigned short X0A[96][8];                  // the six input features per node (fp16, exact), rows of the layer-1 A operand
+    alignas(16) unsigned short X0T[16][96];                 // ... and feature-major: B operand of layer 1's weight gradient
+    alignas(16) float dinv[96];                             // deg^-1/2 (self loop included), 0 for the padding nodes
+    unsigned char ob[96];                                   // open sides of a tile: bit 0 up (n - 9), 1 down, 2 left, 3 right
+};
+static_assert(sizeof(HeadsSmem) <= sizeof(unsigned int) * 8 * 3 * 2 * 64 * 4, "heads scratch aliases FR");
+constexpr int SPLIT_KERNEL_SMEM = (int)sizeof(SplitSmem) > F32_BODY_SMEM ? (int)sizeof(SplitSmem) : F32_BODY_SMEM;
+static_assert(SPLIT_KERNEL_SMEM <= 160 * 1024, "one workgroup per CU");
+__device__ unsigned int g_train_fallbacks = 0;
+constexpr int BWD_SCALE_LOG2 = 7;       // max |dg| s in [128, 256): dP3 = dg s / 81 <= 3.2, 2^14 of headroom, every lo half a normal fp16
+
+__device__ __forceinline__ void trk(float& m, const f32x4 v) {          // largest |x| seen (v_max3_f32 with |.| modifiers)
+    m = fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1])));
+    m = fmaxf(m, fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+__device__ __forceinline__ void mfma_fence(u32x4& a) { asm volatile("s_nop 3" : "+v"(a)); }
+// tile m of a [nodes][16] accumulator image -> dwords 2 (m & 1), + 1 of k block m >> 1 of its hi / lo node-contraction fragments
+__device__ __forceinline__ void split_tile(const f32x4 z, int m, u32x4 (&zh)[3], u32x4 (&zl)[3]) {
+    const int kb = m >> 1, d = 2 * (m & 1);
+    zh[kb][d] = cvt_pk_f16(z[0], z[1]); zh[kb][d + 1] = cvt_pk_f16(z[2], z[3]);
+    zl[kb][d] = lo_pair(zh[kb][d], z[0], z[1]); zl[kb][d + 1] = lo_pair(zh[kb][d + 1], z[2], z[3]);
+}
+__device__ __forceinline__ void plane_store4(unsigned char (&P)[2][PPLANE], int off, const f32x4 v) {
+    const unsigned int h01 = cvt_pk_f16(v[0], v[1]), h23 = cvt_pk_f16(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(&P[0][off]) = (u32x2){h01, h23};
+    *reinterpret_cast<u32x2*>(&P[1][off]) = (u32x2){lo_pair(h01, v[0], v[1]), lo_pair(h23, v[2], v[3])};
+}
+__device__ __forceinline__ bool live_row(int nt, int q, int r) { return nt < 5 || (q == 0 && r == 0); }      // node 16 nt + 4 q + r < 81
+
+// U = X W^T for this wave's 16 columns from the planes (six 16-row tiles, tile 5 = row 80 repeated, x four 32-deep k blocks, three
+// fp16 terms, smallest first); post(m, tile) sees every finished tile before it is split into the node-contraction fragments.
+template <class Post>
+__device__ __forceinline__ void linear_split_post(const unsigned char (&P)[2][PPLANE], const u32x4 (&Bh)[4], const u32x4 (&Bl)[4], int lane,
+                                                  u32x4 (&zh)[3], u32x4 (&zl)[3], Post post) {
+    const int c = lane & 15, q = lane >> 4;
+    u32x4 cur[2], nxt[2];
+    auto frag_off = [&](int step) -> int {
+        const int m = step >> 2, kb = step & 3;
+        return plane_off(m < 5 ? 16 * m + c : 80, 4 * kb + q);
+    };
+    {
+        const int o = frag_off(0);
+        cur[0] = *reinterpret_cast<const u32x4*>(&P[0][o]);
+        cur[1] = *reinterpret_cast<const u32x4*>(&P[1][o]);
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, done = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int step = 0; step < 24; ++step) {
+        const int m = step >> 2, kb = step & 3;
+        if (step < 23) {
+            const int o = frag_off(step + 1);
+            nxt[0] = *reinterpret_cast<const u32x4*>(&P[0][o]);
+            nxt[1] = *reinterpret_cast<const u32x4*>(&P[1][o]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                              // (keeps the 48 fragment reads from being hoisted in a body: 192 registers)
+        f32x4 a = kb == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc;
+        a = mfma_f16(cur[1], Bh[kb], a);
+        a = mfma_f16(cur[0], Bl[kb], a);
+        a = mfma_f16(cur[0], Bh[kb], a);
+        acc = a;
+        // the finished tile m - 1 is masked / checked and split under tile m's first MFMA group
+        if (m > 0 && kb == 0) { post(m - 1, done); split_tile(done, m - 1, zh, zl); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (step < 23) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
+        if (kb == 3) done = acc;
+    }
+    post(5, done);
+    split_tile(done, 5, zh, zl);
+}
+
+// Both forms of the aggregation over the ten blocks (header of this section), node tile by node tile: the blocks of a tile are
+// consecutive, and epi(nt, oT, oR) gets the finished tile (started from the presets pT / pR: bias rows or zero) while the next
+// tile's MFMAs are issued -- only one tile's accumulators are alive at a time.
+template <bool DO_T, bool DO_R, class Epi>
+__device__ __forceinline__ void aggregate_tr(const unsigned int (&AF)[2][AF_BLOCKS][64][4], const u32x4 (&zh)[3], const u32x4 (&zl)[3],
+                                             const f32x4 pT, const f32x4 pR, int lane, Epi epi) {
+    f32x4 oT = pT, oR = pR;
+#pragma unroll
+    for (int blk = 0; blk < AF_BLOCKS; ++blk) {
+        const int kb = af_kb(blk), nt = af_nt(blk);
+        const u32x4 ah = *reinterpret_cast<const u32x4*>(&AF[0][blk][lane][0]);
+        const u32x4 al = *reinterpret_cast<const u32x4*>(&AF[1][blk][lane][0]);
+        if (DO_T) {
+            oT = mfma_f16(zl[kb], ah, oT);
+            oT = mfma_f16(zh[kb], al, oT);
+            oT = mfma_f16(zh[kb], ah, oT);
+        }
+        if (DO_R) {
+            oR = mfma_f16(ah, zl[kb], oR);
+            oR = mfma_f16(al, zh[kb], oR);
+            oR = mfma_f16(ah, zh[kb], oR);
+        }
+        if (blk + 1 == AF_BLOCKS || af_nt(blk + 1) != nt) {
+            epi(nt, oT, oR);
+            oT = pT; oR = pR;
+        }
+    }
+}
+
+// (a real call: inlined into the split body, the heads' ~130 registers on top of the trunk's state spill -- 300 registers, and the
+//  heads alone then take 124 k cycles instead of 25 k; as a callee they get a register allocation of their own)
+//  (the scratch travels as its LDS byte offset and is cast back from the LDS address space inside, so that the callee's accesses are
+//  ds_ instructions, not flat ones)
+typedef __attribute__((address_space(3))) HeadsSmem HeadsSmemLds;
+typedef const __attribute__((address_space(1))) float* gcf;           // pointer arguments in the global address space: global_, not flat_
+typedef __attribute__((address_space(1))) float* gf;
+__device__ __attribute__((noinline)) void heads_board_call(unsigned int sm_lds, int b, gcf w0, gcf w1, gcf w2, gcf w3, gcf w4, gcf w5, gcf w6, gcf w7,
+                                                           gcf pi_all, gcf z_all, const __attribute__((address_space(1))) int64_t* order, int first,
+                                                           int A, int B, gf hp, gf hv, gf lg, gf pol, gf vp, gf val, gf loss, gf dhp, gf dhv) {
+    HeadsSmem& sm = *(HeadsSmem*)reinterpret_cast<HeadsSmemLds*>((size_t)sm_lds);
+    HeadParams Pg;
+    Pg.p[0] = (const float*)w0; Pg.p[1] = (const float*)w1; Pg.p[2] = (const float*)w2; Pg.p[3] = (const float*)w3;
+    Pg.p[4] = (const float*)w4; Pg.p[5] = (const float*)w5; Pg.p[6] = (const float*)w6; Pg.p[7] = (const float*)w7;
+    heads_board<8>(sm, b, nullptr, Pg, (const float*)pi_all, (const float*)z_all, (const int64_t*)order, first, A, B, (float*)hp, (float*)hv, (float*)lg,
+                   (float*)pol, (float*)vp, (float*)val, (float*)loss, (float*)dhp, (float*)dhv, nullptr);
+}
+
+// returns false (to every thread of the workgroup) if a value left fp16 range: the caller redoes the board with the f32 body
+__device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict__ smem, const uint8_t* __restrict__ states72,
+                                                       const int64_t* __restrict__ order, int first,
+                                                       const TrunkParams& tp, const HeadParams& hpm, const float* __restrict__ pi_all,
+                                                       const float* __restrict__ z_all, int A, int B,
+                                                       float* __restrict__ h1, float* __restrict__ h2, float* __restrict__ g_out,
+                                                       float* __restrict__ hp, float* __restrict__ hv, float* __restrict__ lg,
+                                                       float* __restrict__ pol, float* __restrict__ vp, float* __restrict__ val,
+                                                       float* __restrict__ loss, float* __restrict__ dhp, float* __restrict__ dhv,
+                                                       float* __restrict__ part_dW3, float* __restrict__ part_dW2,
+                                                       float* __restrict__ part_dW1, float* __restrict__ part_db) {
+    constexpr int N = 9, V = 81;
+    SplitSmem& sm = *reinterpret_cast<SplitSmem*>(smem);
+    HeadsSmem& hsm = *reinterpret_cast<HeadsSmem*>(&sm.FR[0][0][0][0][0]);
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), q = lane >> 4, c = lane & 15;
+    const int col = 16 * wave + c;
+    const float *W1 = tp.p[0], *b1 = tp.p[1], *W2 = tp.p[2], *b2 = tp.p[3], *W3 = tp.p[4], *b3 = tp.p[5];
+    float mx = 0.f;                                                    // range guard: largest |x| this lane has split
+    TS_DECL
+    // ---- loads that do not depend on the board: biases (both layouts), W1, W2 rows of this wave's columns
+    const f32x4 bT1 = ld4(b1 + 16 * wave + 4 * q), bT2 = ld4(b2 + 16 * wave + 4 * q);
+    const float bR1 = b1[col], bR2 = b2[col], bR3 = b3[col];
+    float w1v[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) w1v[e] = q == 0 ? W1[col * TF + e] : 0.f;
+    f32x4 wf[8];                                                       // W_l[col][32 kb + 8 q + 0..7]: B fragments of the forward linear maps
+    auto request_w = [&](const float* __restrict__ W) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) { wf[2 * kb] = ld4(W + (size_t)col * TH + 32 * kb + 8 * q); wf[2 * kb + 1] = ld4(W + (size_t)col * TH + 32 * kb + 8 * q + 4); }
+    };
+    u32x4 Bh[4], Bl[4];
+    auto split_w = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const f32x4 a = wf[2 * kb], bb = wf[2 * kb + 1];
+            trk(mx, a); trk(mx, bb);
+            Bh[kb] = (u32x4){cvt_pk_f16(a[0], a[1]), cvt_pk_f16(a[2], a[3]), cvt_pk_f16(bb[0], bb[1]), cvt_pk_f16(bb[2], bb[3])};
+            Bl[kb] = (u32x4){lo_pair(Bh[kb][0], a[0], a[1]), lo_pair(Bh[kb][1], a[2], a[3]), lo_pair(Bh[kb][2], bb[0], bb[1]), lo_pair(Bh[kb][3], bb[2], bb[3])};
+            mfma_fence(Bl[kb]);
+        }
+    };
+    request_w(W2);
+    // ---- the board: features, open sides, deg^-1/2
+    const uint8_t* rec = states72 + record_of(order, first, b) * STATE72;
+    if (t < 96) {
+        unsigned short xa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float di = 0.f;
+        int ob = 0;
+        if (t < V) {
+            const QState s = unpack72(rec);
+            const int x = t / N, y = t % N;
+            const bool slot_ok = x < N - 1 && y < N - 1;
+            const int slot = x * (N - 1) + y;
+            const unsigned short one = 0x3C00;
+            xa[0] = t == s.ppos ? one : 0;
+            xa[1] = __builtin_bit_cast(unsigned short, (_Float16)(float)s.pwl);
+            xa[2] = t == s.epos ? one : 0;
+            xa[3] = __builtin_bit_cast(unsigned short, (_Float16)(float)s.ewl);
+            xa[4] = (slot_ok && ((s.hw >> slot) & 1)) ? one : 0;
+            xa[5] = (slot_ok && ((s.vw >> slot) & 1)) ? one : 0;
+            ob = tile_open_bits<N>(s.hw, s.vw, t);
+            di = 1.0f / sqrtf((float)(1 + __popc(ob)));
+        }
+        *reinterpret_cast<u32x4*>(&sm.X0A[t][0]) = (u32x4){xa[0] | ((unsigned)xa[1] << 16), xa[2] | ((unsigned)xa[3] << 16), xa[4] | ((unsigned)xa[5] << 16), 0u};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sm.X0T[k][t] = xa[k];
+        sm.dinv[t] = di;
+        sm.ob[t] = (unsigned char)ob;
+    } else if (t < 96 + 8 * 96 / 2) {
+        reinterpret_cast<unsigned int*>(&sm.X0T[8][0])[t - 96] = 0u;                     // feature rows 8..15 of the padded tile
+    }
+    __syncthreads();
+    TS(9, 0)
+    // ---- A_hat fragments: entry (k-slot e of lane (c, q), block (kb, nt)) = dinv[n] dinv[k] where k is in the closed neighbourhood of n = 16 nt + c
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int blk = wave + 8 * it;                                                   // wave-uniform
+        if (blk < AF_BLOCKS) {
+            const int kb = (AF_KB_PACK >> (2 * blk)) & 3, nt = (AF_NT_PACK >> (3 * blk)) & 7;
+            const int n = 16 * nt + c;
+            const int obn = sm.ob[n];
+            const float dn = sm.dinv[n];
+            float v[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k0 = 32 * kb + 16 * h + 4 * q;
+                const f32x4 dk = *reinterpret_cast<const f32x4*>(&sm.dinv[k0]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int d = k0 + i - n;
+                    const bool adj = d == 0 || (d == -N && (obn & 1)) || (d == N && (obn & 2)) || (d == -1 && (obn & 4)) || (d == 1 && (obn & 8));
+                    v[4 * h + i] = adj ? dn * dk[i] : 0.f;
+                }
+            }
+            u32x4 fh, fl;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { fh[p] = cvt_pk_f16(v[2 * p], v[2 * p + 1]); fl[p] = lo_pair(fh[p], v[2 * p], v[2 * p + 1]); }
+            *reinterpret_cast<u32x4*>(&sm.AF[0][blk][lane][0]) = fh;
+            *reinterpret_cast<u32x4*>(&sm.AF[1][blk][lane][0]) = fl;
+        }
+    }
+    // ---- layer 1, linear: Z1 = X0 W1^T (K = 6 in one 32-deep block; X0 is exact in fp16: two terms)
+    u32x4 zh[3], zl[3];
+    {
+        u32x4 w1h = {cvt_pk_f16(w1v[0], w1v[1]), cvt_pk_f16(w1v[2], w1v[3]), cvt_pk_f16(w1v[4], w1v[5]), 0u};
+        u32x4 w1l = {lo_pair(w1h[0], w1v[0], w1v[1]), lo_pair(w1h[1], w1v[2], w1v[3]), lo_pair(w1h[2], w1v[4], w1v[5]), 0u};
+        mfma_fence(w1l);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            u32x4 xa = *reinterpret_cast<const u32x4*>(&sm.X0A[m < 5 ? 16 * m + c : 80][0]);
+            if (q != 0) xa = (u32x4){0u, 0u, 0u, 0u};
+            f32x4 z = mfma_f16(xa, w1l, (f32x4){0.f, 0.f, 0.f, 0.f});
+            z = mfma_f16(xa, w1h, z);
+            trk(mx, z);
+            split_tile(z, m, zh, zl);
+        }
+    }
+    __syncthreads();                                                   // A_hat fragments complete
+    TS(9, 1)
+    // ---- forward epilogues
+    const int poff = (2 * wave + (q >> 1)) /* 16-byte slot of features 16 w + 4 q .. */, pbyte = 8 * (q & 1);
+    auto store_plane_tile = [&](int nt, f32x4 v, bool relu) {          // T form: lane = node c of tile nt, features 16 w + 4 q + r
+        trk(mx, v);
+        if (relu) v = relu4(v);
+        if (nt < 5 || c == 0) plane_store4(sm.P, plane_off(16 * nt + c, poff) + pbyte, v);
+    };
+    unsigned int msk[3] = {0u, 0u, 0u};                                 // ReLU masks of the three layers: bit 4 nt + r, R layout
+    u32x4 hh[3], hl[3];                                                 // R form of H_l (lane = feature c, nodes 16 nt + 4 q + r) as fragments
+    auto park_tile = [&](int nt, f32x4 v, unsigned int& m) {
+        trk(mx, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (v[r] > 0.f && live_row(nt, q, r)) m |= 1u << (4 * nt + r);
+        v = relu4(v);
+        split_tile(v, nt, hh, hl);
+    };
+    auto park_store = [&](float* __restrict__ hpark) {
+        u32x4* dst = reinterpret_cast<u32x4*>(hpark + (size_t)b * 96 * TH) + (size_t)wave * 6 * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) { dst[(2 * kb) * 64] = hh[kb]; dst[(2 * kb + 1) * 64] = hl[kb]; }
+    };
+    // ---- layer 1: aggregation, planes of H1, parked fragments of H1
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) mfma_fence(zl[kb]);
+    aggregate_tr<true, true>(sm.AF, zh, zl, bT1, (f32x4){bR1, bR1, bR1, bR1}, lane, [&](int nt, const f32x4& oT, const f32x4& oR) {
+        store_plane_tile(nt, oT, true);
+        park_tile(nt, oR, msk[0]);
+    });
+    park_store(h1);
+    split_w();                                                          // W2 fragments
+    request_w(W3);
+    __syncthreads();                                                    // planes of H1 complete
+    TS(9, 2)
+    // ---- layer 2
+    linear_split_post(sm.P, Bh, Bl, lane, zh, zl, [&](int, f32x4& z) { trk(mx, z); });
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) mfma_fence(zl[kb]);
+    __syncthreads();                                                    // everybody has read the planes of H1
+    TS(9, 3)
+    aggregate_tr<true, true>(sm.AF, zh, zl, bT2, (f32x4){bR2, bR2, bR2, bR2}, lane, [&](int nt, const f32x4& oT, const f32x4& oR) {
+        store_plane_tile(nt, oT, true);
+        park_tile(nt, oR, msk[1]);
+    });
+    park_store(h2);
+    split_w();                                                          // W3 fragments
+    __syncthreads();                                                    // planes of H2 complete
+    TS(9, 4)
+    // ---- layer 3 (R form only: its ReLU mask and the mean pool; H3 itself is not needed again)
+    linear_split_post(sm.P, Bh, Bl, lane, zh, zl, [&](int, f32x4& z) { trk(mx, z); });
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) mfma_fence(zl[kb]);
+    {
+        float s = 0.f;
+        aggregate_tr<false, true>(sm.AF, zh, zl, bT2, (f32x4){bR3, bR3, bR3, bR3}, lane, [&](int nt, const f32x4&, const f32x4& oR) {
+            trk(mx, oR);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (oR[r] > 0.f && live_row(nt, q, r)) { msk[2] |= 1u << (4 * nt + r); s += oR[r]; }
+        });
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        s /= (float)V;                                                  // global_mean_pool
+        // (FR, which the heads' scratch aliases, is first written in the backward pass)
+        if (q == 0) { hsm.gs[col] = s; g_out[(size_t)b * TH + col] = s; }
+    }
+    // the backward pass's own operands, requested under the heads: W3^T fragments and this wave's parked H2
+    float wt[32];                                                       // W_l[32 kb + 8 q + e][col]: B fragments of the data gradients
+    auto request_wt = [&](const float* __restrict__ W) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) wt[i] = W[(size_t)(32 * (i >> 3) + 8 * q + (i & 7)) * TH + col];
+    };
+    auto split_wt = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float a0 = wt[8 * kb + 2 * p], a1 = wt[8 * kb + 2 * p + 1];
+                mx = fmaxf(mx, fmaxf(fabsf(a0), fabsf(a1)));
+                Bh[kb][p] = cvt_pk_f16(a0, a1);
+                Bl[kb][p] = lo_pair(Bh[kb][p], a0, a1);
+            }
+            mfma_fence(Bl[kb]);
+        }
+    };
+    auto request_h = [&](const float* __restrict__ hpark) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(hpark + (size_t)b * 96 * TH) + (size_t)wave * 6 * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) { hh[kb] = src[(2 * kb) * 64]; hl[kb] = src[(2 * kb + 1) * 64]; }
+    };
+    TS(9, 5)
+    // ---- heads, losses, head gradients (its first barrier publishes gs)
+    heads_board_call((unsigned int)(size_t)(HeadsSmemLds*)&hsm, b, (gcf)hpm.p[0], (gcf)hpm.p[1], (gcf)hpm.p[2], (gcf)hpm.p[3], (gcf)hpm.p[4], (gcf)hpm.p[5],
+                     (gcf)hpm.p[6], (gcf)hpm.p[7], (gcf)pi_all, (gcf)z_all, (const __attribute__((address_space(1))) int64_t*)order, first, A, B,
+                     (gf)hp, (gf)hv, (gf)lg, (gf)pol, (gf)vp, (gf)val, (gf)loss, (gf)dhp, (gf)dhv);
+    TS(9, 6)
+    request_wt(W3);                                                     // (behind the heads: they hold ~100 weight registers of their own)
+    request_h(h2);
+    // ---- backward.  dg = hsm.dgv; scaled by a power of two s with max |dg| s in [128, 256)
+    float dgs, inv_s;
+    {
+        const float d0 = hsm.dgv[lane], d1 = hsm.dgv[64 + lane];
+        const float m = wave_max(fmaxf(fabsf(d0), fabsf(d1)));
+        const int e = (__builtin_bit_cast(int, m) >> 23) & 0xFF;
+        int es = 254 + BWD_SCALE_LOG2 - e;                              // biased exponent of s = 2^(BWD_SCALE_LOG2 - (e - 127))
+        es = (e == 0 || e == 255) ? 127 : min(max(es, 1), 254);
+        const float s = __builtin_bit_cast(float, es << 23);
+        inv_s = 1.0f / s;
+        dgs = hsm.dgv[col] * s / (float)V;                              // global_mean_pool backward, this lane's column
+    }
+    __syncthreads();                                                    // the heads' scratch is dead: FR may be written
+    auto store_db = [&](float sdb, int layer) {
+        sdb += __shfl_xor(sdb, 16);
+        sdb += __shfl_xor(sdb, 32);
+        if (q == 0) part_db[((size_t)layer * B + b) * TH + col] = sdb * inv_s;
+    };
+    u32x4 ah[3], al[3];                                                 // R form of dZ_l: A fragments of dW_l
+    auto publish_dz = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) {
+            *reinterpret_cast<u32x4*>(&sm.FR[wave][kb][0][lane][0]) = ah[kb];
+            *reinterpret_cast<u32x4*>(&sm.FR[wave][kb][1][lane][0]) = al[kb];
+        }
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto aggregate_back = [&](bool planes) {
+        if (planes)
+            aggregate_tr<true, true>(sm.AF, zh, zl, zero4, zero4, lane, [&](int nt, const f32x4& oT, const f32x4& oR) {
+                store_plane_tile(nt, oT, false);                        // dZ_l: A operand of the next data gradient
+                trk(mx, oR);
+                split_tile(oR, nt, ah, al);
+            });
+        else
+            aggregate_tr<false, true>(sm.AF, zh, zl, zero4, zero4, lane, [&](int nt, const f32x4&, const f32x4& oR) {
+                trk(mx, oR);
+                split_tile(oR, nt, ah, al);
+            });
+    };
+    auto weight_grad = [&](float* __restrict__ pdW) {                   // dW_l[all j][this wave's k]: A = FR (all waves), B = parked H_{l-1}
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) mfma_fence(hl[kb]);              // (loaded, not computed: harmless)
+#pragma unroll
+        for (int jt = 0; jt < 8; ++jt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) {
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(&sm.FR[jt][kb][0][lane][0]);
+                const u32x4 al = *reinterpret_cast<const u32x4*>(&sm.FR[jt][kb][1][lane][0]);
+                o = mfma_f16(al, hh[kb], o);
+                o = mfma_f16(ah, hl[kb], o);
+                o = mfma_f16(ah, hh[kb], o);
+            }
+            float* dst = pdW + (size_t)b * TH * TH + (size_t)(16 * jt + 4 * q) * TH + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(size_t)r * TH] = o[r] * inv_s;
+        }
+    };
+    // layer 3: dP3 = dg / V on the nodes whose H3 is positive
+    {
+        float sdb = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = ((msk[2] >> (4 * nt + r)) & 1u) ? dgs : 0.f; sdb += v[r]; }
+            split_tile(v, nt, zh, zl);
+        }
+        mx = fmaxf(mx, fabsf(dgs));
+        store_db(sdb, 2);
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) mfma_fence(zl[kb]);
+        aggregate_back(true);                                           // (every wave left the planes of H2 long ago)
+        publish_dz();
+        split_wt();                                                     // W3^T fragments
+        request_wt(W2);
+        __syncthreads();                                                // planes and fragments of dZ3 complete
+        TS(9, 7)
+        weight_grad(part_dW3);
+        request_h(h1);
+        TS(9, 8)
+    }
+    // layers 2 and 1: dH_l = dZ_{l+1} W_{l+1}, masked by H_l > 0
+    auto masked_linear = [&](unsigned int m, int layer) {
+        float sdb = 0.f;
+#ifdef AQG_TRAIN_DEBUG
+        if (layer == 1)            // the planes hold dZ3 / s: dense dump of hi + lo
+            for (int i = t; i < V * TH; i += 512) {
+                const int n = i / TH, f = i % TH, o = plane_off(n, f >> 3) + 2 * (f & 7);
+                DBG_PUT(2, B, b, n, f, ((float)*reinterpret_cast<const _Float16*>(&sm.P[0][o]) + (float)*reinterpret_cast<const _Float16*>(&sm.P[1][o])) * inv_s)
+            }
+#endif
+        linear_split_post(sm.P, Bh, Bl, lane, zh, zl, [&](int mt, f32x4& z) {
+#ifdef AQG_TRAIN_DEBUG
+            if (layer == 1) for (int r = 0; r < 4; ++r) if (live_row(mt, q, r)) DBG_PUT(1, B, b, 16 * mt + 4 * q + r, col, z[r] * inv_s)
+#endif
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { if (!((m >> (4 * mt + r)) & 1u)) z[r] = 0.f; sdb += z[r]; }
+#ifdef AQG_TRAIN_DEBUG
+            if (layer == 1) for (int r = 0; r < 4; ++r) if (live_row(mt, q, r)) DBG_PUT(0, B, b, 16 * mt + 4 * q + r, col, z[r] * inv_s)
+#endif
+            trk(mx, z);
+        });
+        store_db(sdb, layer);
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) mfma_fence(zl[kb]);
+    };
+    {
+        masked_linear(msk[1], 1);
+        TS(9, 9)
+        __syncthreads();                                                // everybody has read the planes of dZ3 (and FR: weight_grad is behind)
+        aggregate_back(true);
+        publish_dz();
+        split_wt();                                                     // W2^T fragments
+        __syncthreads();
+        TS(9, 10)
+        weight_grad(part_dW2);
+        TS(9, 11)
+    }
+    {
+        masked_linear(msk[0], 0);
+        TS(9, 12)
+        aggregate_back(false);
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) mfma_fence(al[kb]);
+        // dW1[this wave's j][k < 6] = sum_n dZ1[n][j] X0[n][k]: A = own fragments, B = the feature-major X0 image (exact: two terms)
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) {
+            const u32x2 x0 = *reinterpret_cast<const u32x2*>(&sm.X0T[c][32 * kb + 4 * q]);
+            const u32x2 x1 = *reinterpret_cast<const u32x2*>(&sm.X0T[c][32 * kb + 16 + 4 * q]);
+            const u32x4 xb = {x0[0], x0[1], x1[0], x1[1]};
+            o = mfma_f16(al[kb], xb, o);
+            o = mfma_f16(ah[kb], xb, o);
+        }
+        if (c < TF) {
+            float* dst = part_dW1 + (size_t)b * TH * TF + (size_t)(16 * wave + 4 * q) * TF + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[r * TF] = o[r] * inv_s;
+        }
+        TS(9, 13)
+    }
+    return !__syncthreads_or(!(mx <= 65504.0f));
+}
+
+// option "train_fused" = 3 forces the fallback for every board (tests)
+__global__ __launch_bounds__(512) void train_board_split_kernel(const uint8_t* __restrict__ states72, const int64_t* __restrict__ order, int first,
+                                                                TrunkParams tp, HeadParams hpm, const float* __restrict__ pi_all,
+                                                                const float* __restrict__ z_all, int A, int B, int force_fallback,
+                                                                float* __restrict__ h1, float* __restrict__ h2, float* __restrict__ g_out,
+                                                                float* __restrict__ hp, float* __restrict__ hv, float* __restrict__ lg,
+                                                                float* __restrict__ pol, float* __restrict__ vp, float* __restrict__ val,
+                                                                float* __restrict__ loss, float* __restrict__ dhp, float* __restrict__ dhv,
+                                                                float* __restrict__ part_dW3, float* __restrict__ part_dW2,
+                                                                float* __restrict__ part_dW1, float* __restrict__ part_db) {
+    __shared__ __align__(16) unsigned char smem[SPLIT_KERNEL_SMEM];
+    const bool ok = train_board_split_body(smem, states72, order, first, tp, hpm, pi_all, z_all, A, B, h1, h2, g_out, hp, hv, lg, pol, vp, val,
+                                           loss, dhp, dhv, part_dW3, part_dW2, part_dW1, part_db);
+    if (ok && !force_fallback) return;
+    if (threadIdx.x == 0) atomicAdd(&g_train_fallbacks, 1u);
+    __syncthreads();
+    train_board_f32_body<9>(smem, states72, order, first, tp, hpm, pi_all, z_all, A, B, 96, h1, h2, g_out, hp, hv, lg, pol, vp, val, loss,
+                            dhp, dhv, part_dW3, part_dW2, part_dW1, part_db);
+}
 
 // ---------------------------------------------------------------------------------------------
 // gradient of every parameter element + its Adam update.   One thread per element of the 14 tensors.
@@ -923,33 +1505,47 @@ struct FinalJobs {
     int B, A, compute, update;
     float lr, beta1, beta2, eps, bc1, bc2_sqrt;
 };
-__device__ __forceinline__ void adam_update(const FinalJobs& jb, int i, unsigned int e, float gr) {
-    const float mi = jb.beta1 * jb.m[i][e] + (1.f - jb.beta1) * gr;          // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = jb.beta2 * jb.v[i][e] + (1.f - jb.beta2) * gr * gr;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+// (the old state is fetched by adam_fetch() BEFORE the gradient's own loads: one memory round trip per workgroup instead of two)
+struct AdamOld { float m, v, p; };
+__device__ __forceinline__ AdamOld adam_fetch(const FinalJobs& jb, int i, unsigned int e) { return AdamOld{jb.m[i][e], jb.v[i][e], jb.p[i][e]}; }
+__device__ __forceinline__ void adam_update(const FinalJobs& jb, int i, unsigned int e, float gr, const AdamOld& o) {
+    const float mi = jb.beta1 * o.m + (1.f - jb.beta1) * gr;          // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = jb.beta2 * o.v + (1.f - jb.beta2) * gr * gr;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     jb.m[i][e] = mi; jb.v[i][e] = vi;
     const float denom = sqrtf(vi) / jb.bc2_sqrt + jb.eps;
-    jb.p[i][e] -= (jb.lr / jb.bc1) * (mi / denom);
+    jb.p[i][e] = o.p - (jb.lr / jb.bc1) * (mi / denom);
 }
 // A workgroup = 32 lanes x 8 board groups: a thread sums its group's boards in order, the 8 group sums are added in group
 // order -- a fixed summation order with 8x the loads in flight of one thread per element.  The first FINAL_BIG_BLOCKS
 // workgroups take the two [128,128] trunk weights four elements per lane (16-byte loads of the 16 MB of per-board
 // partials); the rest take every other tensor one element per lane (end[] counts those tensors only).
+// A "row" = such a team of 256 threads; a workgroup = FINAL_TEAMS rows (1,246 four-wave workgroups took longer to LAUNCH than to
+// run: the same rows as 312 sixteen-wave workgroups).
 constexpr int FINAL_BIG_BLOCKS = 2 * TH * TH / 128;
-__global__ __launch_bounds__(256) void train_final_kernel(FinalJobs jb) {
-    __shared__ f32x4 red4[8][33];
+constexpr int FINAL_TEAMS = 4;
+__global__ __launch_bounds__(256 * FINAL_TEAMS) void train_final_kernel(FinalJobs jb) {
+    __shared__ f32x4 red4s[FINAL_TEAMS][8][33];
     TS_DECL
-    const int le = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int team = threadIdx.x >> 8, tt = threadIdx.x & 255;
+    const unsigned int row = blockIdx.x * FINAL_TEAMS + team;
+    f32x4 (*red4)[33] = red4s[team];
+    const int le = tt & 31, grp = tt >> 5;
     const int B = jb.B, A = jb.A;
     const int per = (B + 7) / 8, b0 = grp * per, b1 = min(B, b0 + per);
-    if (blockIdx.x < FINAL_BIG_BLOCKS) {
-        const unsigned int q4 = blockIdx.x * 32 + le;             // float4 index over gcn1.w then gcn2.w
+    if (row < FINAL_BIG_BLOCKS) {
+        const unsigned int q4 = row * 32 + le;                    // float4 index over gcn1.w then gcn2.w
         const int i = q4 < TH * TH / 4 ? 2 : 4;
         const unsigned int e = (q4 & (TH * TH / 4 - 1)) * 4;
         f32x4 gr4;
+        AdamOld old[4];
+        if (jb.update && grp == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) old[k] = adam_fetch(jb, i, e + k);
+        }
         if (jb.compute) {
             const float* src = jb.part_dW[i >> 1] + e;
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
+#pragma unroll 16
             for (int b = b0; b < b1; ++b) s += ld4(src + (size_t)b * TH * TH);
             red4[grp][le] = s;
             __syncthreads();
@@ -963,40 +1559,52 @@ __global__ __launch_bounds__(256) void train_final_kernel(FinalJobs jb) {
         }
         if (jb.update) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) adam_update(jb, i, e + k, gr4[k]);
+            for (int k = 0; k < 4; ++k) adam_update(jb, i, e + k, gr4[k], old[k]);
         }
         return;
     }
     float (*red)[33] = reinterpret_cast<float (*)[33]>(&red4[0][0]);
-    const unsigned int e0 = (blockIdx.x - FINAL_BIG_BLOCKS) * 32 + le;
+    const unsigned int e0 = (row - FINAL_BIG_BLOCKS) * 32 + le;
     const unsigned int total = jb.end[13] + (jb.loss_sums ? 2u : 0u);
     const bool live = e0 < total;
     int i = 0;
     if (live) while (i < 14 && e0 >= jb.end[i]) ++i;
     const unsigned int e = e0 - (i ? jb.end[i - 1] : 0u);
     TS(6, 0)
+    AdamOld old{0.f, 0.f, 0.f};
+    if (jb.update && grp == 0 && live && i < 14) old = adam_fetch(jb, i, e);
     if (jb.compute) {
         float s = 0.f;
         if (!live) {
         } else if (i < 6) {
-            if (i & 1) { const float* src = jb.part_db[i >> 1] + e; for (int b = b0; b < b1; ++b) s += src[(size_t)b * TH]; }
-            else { const float* src = jb.part_dW[0] + e; for (int b = b0; b < b1; ++b) s += src[(size_t)b * TH * TF]; }       // gcn0.w
+            if (i & 1) {
+                const float* src = jb.part_db[i >> 1] + e;
+#pragma unroll 16
+                for (int b = b0; b < b1; ++b) s += src[(size_t)b * TH];
+            } else {
+                const float* src = jb.part_dW[0] + e;                                                                      // gcn0.w
+#pragma unroll 16
+                for (int b = b0; b < b1; ++b) s += src[(size_t)b * TH * TF];
+            }
         } else if (i == 6 || i == 10) {
             const int j = e / TH, k = e % TH;
             const float* d = (i == 6 ? jb.dhp : jb.dhv) + j;
             const float* x = jb.gp + k;
-#pragma unroll 8
+#pragma unroll 16
             for (int b = b0; b < b1; ++b) s = fmaf(d[(size_t)b * HH], x[(size_t)b * TH], s);
         } else if (i == 7 || i == 11) {
             const float* d = (i == 7 ? jb.dhp : jb.dhv) + e;
+#pragma unroll 16
             for (int b = b0; b < b1; ++b) s += d[(size_t)b * HH];
         } else if (i == 8) {
             const int a = e / HH, j = e % HH;
-#pragma unroll 8
+#pragma unroll 16
             for (int b = b0; b < b1; ++b) s = fmaf(jb.dlg[(size_t)b * A + a], jb.hp[(size_t)b * HH + j], s);
         } else if (i == 9) {
+#pragma unroll 16
             for (int b = b0; b < b1; ++b) s += jb.dlg[(size_t)b * A + e];
         } else if (i == 12) {
+#pragma unroll 16
             for (int b = b0; b < b1; ++b) s = fmaf(jb.dvp[b], jb.hv[(size_t)b * HH + e], s);
         } else if (i == 13) {
             for (int b = b0; b < b1; ++b) s += jb.dvp[b];
@@ -1016,13 +1624,22 @@ __global__ __launch_bounds__(256) void train_final_kernel(FinalJobs jb) {
         if (i == 14) return;
         gr = jb.g[i][e];
     }
-    if (jb.update) adam_update(jb, i, e, gr);
+    if (jb.update) adam_update(jb, i, e, gr, old);
 }
 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-int g_train_fused = 1;    // aqg_set_option("train_fused"): 1 = one workgroup per position for the whole forward + backward, 0 = six launches
+// aqg_set_option("train_fused"): 2 (default) = one workgroup per position, contractions in fp16 split precision on the 9x9 board (other
+// boards: as 1);  1 = one workgroup per position, f32-input MFMA;  0 = six launches;  3 = as 2 with every board sent through the
+// f32 fallback (tests)
+int g_train_fused = 2;
+long long train_fallbacks(int reset) {
+    unsigned int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_train_fallbacks), sizeof(v)) != hipSuccess) return -1;
+    if (reset) { const unsigned int z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_train_fallbacks), &z, sizeof(z)) != hipSuccess) return -1; }
+    return (long long)v;
+}
 
 template <int N>
 static void launch_forward_backward(const aqg_train& t, const uint8_t* states72, const float* pi, const float* z, const int64_t* order,
@@ -1038,8 +1655,12 @@ static void launch_forward_backward(const aqg_train& t, const uint8_t* states72,
         for (int i = 0; i < 6; ++i) tpm.p[i] = P[i];
         HeadParams hpm;
         for (int i = 0; i < 8; ++i) hpm.p[i] = P[6 + i];
-        hipLaunchKernelGGL(train_board_kernel<N>, dim3(B), dim3(512), 0, st, states72, order, first, tpm, hpm, pi, z, A, B, t.h1, t.h2, t.g,
-                           t.hp, t.hv, t.lg, t.pol, t.vp, t.val, t.loss, t.dhp, t.dhv, pdW3, pdW2, pdW1, pdb);
+        if (N == 9 && g_train_fused >= 2)      // h1 / h2 hold 96 rows per board here: the parked fragments (and the fallback's rows)
+            hipLaunchKernelGGL(train_board_split_kernel, dim3(B), dim3(512), 0, st, states72, order, first, tpm, hpm, pi, z, A, B, g_train_fused == 3 ? 1 : 0,
+                               t.h1, t.h2, t.g, t.hp, t.hv, t.lg, t.pol, t.vp, t.val, t.loss, t.dhp, t.dhv, pdW3, pdW2, pdW1, pdb);
+        else
+            hipLaunchKernelGGL(train_board_kernel<N>, dim3(B), dim3(512), 0, st, states72, order, first, tpm, hpm, pi, z, A, B, N * N, t.h1, t.h2, t.g,
+                               t.hp, t.hv, t.lg, t.pol, t.vp, t.val, t.loss, t.dhp, t.dhv, pdW3, pdW2, pdW1, pdb);
         return;
     }
     const dim3 grid(2 * B), block(256);
@@ -1085,7 +1706,8 @@ static int launch_final(const aqg_train& t, int B, bool compute, bool update, in
     jb.B = B; jb.A = A; jb.compute = compute; jb.update = update;
     const double bc1 = 1.0 - pow((double)t.beta1, (double)step), bc2 = 1.0 - pow((double)t.beta2, (double)step);
     jb.lr = t.lr; jb.beta1 = t.beta1; jb.beta2 = t.beta2; jb.eps = t.eps; jb.bc1 = (float)bc1; jb.bc2_sqrt = (float)sqrt(bc2);
-    hipLaunchKernelGGL(train_final_kernel, dim3(FINAL_BIG_BLOCKS + (run + 2 + 31) / 32), dim3(256), 0, st, jb);
+    const unsigned int rows = FINAL_BIG_BLOCKS + (run + 2 + 31) / 32;
+    hipLaunchKernelGGL(train_final_kernel, dim3((rows + FINAL_TEAMS - 1) / FINAL_TEAMS), dim3(256 * FINAL_TEAMS), 0, st, jb);
     return check_launch("train_final_kernel");
 }
 
@@ -1136,6 +1758,9 @@ int train_steps(const aqg_train& t, const uint8_t* states72, const float* pi, co
     return 0;
 }
 
+#ifdef AQG_TRAIN_DEBUG
+extern "C" int aqg_debug_train_buf(float* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_train_dbg), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
+#endif
 #ifdef AQG_STAMP
 extern "C" int aqg_debug_train_stamps(unsigned long long* out_host, int reset) {
     if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_train_stamp), sizeof(unsigned long long) * 160) != hipSuccess) return -1;

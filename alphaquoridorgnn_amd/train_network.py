@@ -67,7 +67,8 @@ class GNNTrainer:
         B, V, A, H = self.max_batch, self.V, self.A, HIDDEN_DIM
         f = dict(dtype=torch.float32, device=self.dev)
         w = self.ws = dict(
-            h1=torch.empty((B * V, H), **f), h2=torch.empty((B * V, H), **f), h3=torch.empty((B * V, H), **f),
+            h1=torch.empty((B * 96, H), **f), h2=torch.empty((B * 96, H), **f),    # 96 rows per position: include/aqgnn.h
+            h3=torch.empty((B * V, H), **f),
             zbuf=torch.empty((B * V, H), **f), dh=torch.empty((B * V, H), **f),
             g=torch.empty((B, H), **f), dg=torch.empty((B, H), **f), hp=torch.empty((B, H // 2), **f),
             hv=torch.empty((B, H // 2), **f), dhp=torch.empty((B, H // 2), **f), dhv=torch.empty((B, H // 2), **f),

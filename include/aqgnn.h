@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define AQG_MAX_LEGAL 136 /* >= 5 pawn moves + 128 wall placements */
-#define AQG_ABI_VERSION 7
+#define AQG_ABI_VERSION 8
 
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
@@ -38,8 +38,11 @@ const char* aqg_last_error(void);
  * 4-wave x 2-per-CU form, 7 = the pair form (one workgroup per CU, two boards per pass: measured slower, kept as evidence); "step_variant" 1/0 = one-load-round MCTS step / round-1 step, "step_fast_depth" = tree depth at which
  * the fast step hands over to memory mode; "trunk_prio" = static wave priorities in the trunk (-1 = by launch size, default); "step_prio" 0..3 / "heads_prio" 0/1 = wave
  * priority of the MCTS step / heads kernels (defaults 1 / 0); "step_waves" = games per step workgroup (4);
- * "fuse_heads" 1 = heads inside the trunk workgroup (measured slower, default 0); "train_fused" 1/0 = training step as one
- * workgroup per position / as the six-launch column-split chain (csrc/gcn_train.hip);
+ * "fuse_heads" 1 = heads inside the trunk workgroup (measured slower, default 0); "train_fused" = form of the training step
+ * (csrc/gcn_train.hip): 2 (default) one workgroup per position with every contraction in fp16 split precision on the 16-bit
+ * matrix pipe (9x9 board; a position whose values leave fp16 range is redone in f32 inside the same launch, counted by
+ * aqg_gcn_train_fallbacks), 1 one workgroup per position with f32-input MFMA, 0 the six-launch column-split chain, 3 = 2 with
+ * every position sent through the f32 fallback (tests);
  * "trunk_phase_delay" = start offset of the second- / third-resident workgroups in units of 64 cycles, applied to
  * launches of at least "trunk_delay_min_boards" boards; "use_graph" 0/1 = replay
  * a move's 3*sims+2 launches as one captured hipGraph when the stream is capturable (default 1); "profile_trunk" 0/1/2 = no event pairs / around trunk launches / around MCTS step launches */
@@ -235,7 +238,9 @@ typedef struct aqg_train {
     float lr, beta1, beta2, eps;  /* 1e-3 * LambdaLR factor (train_network.py:56-66), 0.9, 0.999, 1e-8 */
     float* params[14]; float* grads[14]; float* adam_m[14]; float* adam_v[14];
     /* workspace */
-    float* h1; float* h2; float* h3;  /* [B*V, 128] post-ReLU activations of the three GCN layers */
+    float* h1; float* h2;         /* [B*96, 128] (96 rows per position on every board size): post-ReLU activations of layers 1, 2 -- node
+                                   * rows in the f32 forms, this round's parked fp16 hi / lo fragments in the split form */
+    float* h3;                    /* [B*V, 128] layer 3 (six-launch form only) */
     float* zbuf; float* dh;       /* [B*V, 128] dZ = A_hat dP of layer 3 / layer 2 (the next launch contracts over full rows) */
     float* g; float* dg;          /* [B, 128]   pooled features and their gradient */
     float* hp; float* hv; float* dhp; float* dhv;   /* [B, 64] head hidden layers and gradients */
@@ -255,6 +260,9 @@ int aqg_gcn_train_step(const aqg_train* t_host, const uint8_t* states72, const f
  * loss_sums[2] (device, may be NULL) -- the per-epoch sums train_network.py:89-90 prints. */
 int aqg_gcn_train_steps(const aqg_train* t_host, const uint8_t* states72, const float* pi_target, const float* z_target,
                         const int64_t* order, long long positions, float* loss_sums, void* stream);
+/* Positions that the split-precision step ("train_fused" 2) has redone in f32 since the last reset (synchronises the device);
+ * -1 on error.  A diagnostic: results do not depend on it. */
+long long aqg_gcn_train_fallbacks(int reset);
 
 /* ------------------------------------------------------------------ CPU baseline agents (agents.py) -- HOST pointers, host code */
 

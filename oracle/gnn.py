@@ -137,7 +137,7 @@ def forward_states_dense(params, recs, chunk=1024):
     that the two agree to 1e-12 on reference-walk states, so the slow form stays the statement and this one the tool."""
     recs = np.asarray(recs, dtype=np.uint8).reshape(-1, 72)
     p = {k: np.asarray(v, dtype=np.float64) for k, v in params.items()}
-    outs = []
+    outs, margins = [], []
     for c0 in range(0, recs.shape[0], chunk):
         r = recs[c0:c0 + chunk]
         B = r.shape[0]
@@ -174,17 +174,41 @@ def forward_states_dense(params, recs, chunk=1024):
         x[:, tw, 4] = (r[:, 4:4 + S * S] == 1)
         x[:, tw, 5] = (r[:, 4:4 + S * S] == 2)
         h = x
+        margin = np.full(B, np.inf)
         for l in range(3):
-            h = np.maximum(An @ (h @ p[f"gcn_layers.{l}.lin.weight"].T) + p[f"gcn_layers.{l}.bias"], 0.0)
+            pre = An @ (h @ p[f"gcn_layers.{l}.lin.weight"].T) + p[f"gcn_layers.{l}.bias"]
+            margin = np.minimum(margin, _kink_margin(pre.reshape(B, -1)))
+            h = np.maximum(pre, 0.0)
         outs.append(h.mean(1))
+        margins.append(margin)
     g = np.concatenate(outs, 0) if outs else np.zeros((0, 128))
-    hp = np.maximum(g @ p["policy_head.0.weight"].T + p["policy_head.0.bias"], 0.0)
+    pre_p = g @ p["policy_head.0.weight"].T + p["policy_head.0.bias"]
+    hp = np.maximum(pre_p, 0.0)
     logits = hp @ p["policy_head.2.weight"].T + p["policy_head.2.bias"]
-    hv = np.maximum(g @ p["value_head.0.weight"].T + p["value_head.0.bias"], 0.0)
+    pre_v = g @ p["value_head.0.weight"].T + p["value_head.0.bias"]
+    hv = np.maximum(pre_v, 0.0)
     vpre = hv @ p["value_head.2.weight"].T + p["value_head.2.bias"]
     e = np.exp(logits - logits.max(axis=1, keepdims=True))
+    margin = np.concatenate(margins) if margins else np.zeros((0,))
+    if margin.size:
+        margin = np.minimum(margin, np.minimum(_kink_margin(pre_p), _kink_margin(pre_v)))
     return dict(pooled=g, logits=logits, value_pre=vpre[:, 0], policy=e / e.sum(axis=1, keepdims=True),
-                value=np.tanh(vpre[:, 0]))
+                value=np.tanh(vpre[:, 0]), relu_margin=margin)
+
+
+def _kink_margin(pre):
+    """Per row: the smallest NON-ZERO |pre-activation| (an exact zero takes the same ReLU branch in every arithmetic)."""
+    a = np.abs(pre)
+    a = np.where(a == 0.0, np.inf, a)
+    return a.min(axis=1)
+
+
+def relu_margins(params, recs):
+    """Distance of every position from its nearest ReLU kink: min non-zero |pre-activation| over the three GCN layers and the
+    two head hidden layers (fp64).  Below ~1e-7 the branch -- and with it one whole element of the backward pass -- is decided
+    by rounding in ANY fp32 implementation, the reference's own included; the gradient parity tests draw their positions
+    from those at least 1e-6 away (tests/test_gpu_parity.py::_train_batch)."""
+    return forward_states_dense(params, recs)["relu_margin"]
 
 
 def init_params(seed=0, N=9, num_features=6, hidden=128, layers=3):

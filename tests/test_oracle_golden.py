@@ -199,3 +199,25 @@ def test_gnn_oracle_dense_form_equals_edge_list_form(N):
     a, b = og.forward_states(p, recs), og.forward_states_dense(p, recs, chunk=50)
     for k in a:
         assert np.abs(a[k] - b[k]).max() < 1e-12, k
+
+
+def test_relu_margins_match_the_edge_list_form():
+    """oracle/gnn.py::relu_margins (dense form, what the gradient parity tests filter their positions with) against the smallest
+    non-zero |pre-activation| recomputed layer by layer with the edge-list GCNConv."""
+    from oracle import gnn as og
+    params = og.init_params(3)
+    recs = U.golden("walk_9x9.npz")["states"][5:400:60]
+    got = og.relu_margins(params, recs)
+    p = {k: np.asarray(v, dtype=np.float64) for k, v in params.items()}
+    for i, rec in enumerate(recs):
+        h, e = og.node_features(rec).astype(np.float64), og.board_edges(rec)
+        smallest = np.inf
+        for l in range(3):
+            pre = og.gcn_conv(h, e, p[f"gcn_layers.{l}.lin.weight"], p[f"gcn_layers.{l}.bias"])
+            smallest = min(smallest, np.abs(pre[pre != 0]).min())
+            h = np.maximum(pre, 0.0)
+        g = h.mean(0)
+        for head in ("policy_head", "value_head"):
+            pre = g @ p[f"{head}.0.weight"].T + p[f"{head}.0.bias"]
+            smallest = min(smallest, np.abs(pre[pre != 0]).min())
+        assert abs(got[i] - smallest) <= 1e-12 + 1e-6 * smallest

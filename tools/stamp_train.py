@@ -15,7 +15,7 @@ from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
 from alphaquoridorgnn_amd.train_network import GNNTrainer, BATCH_SIZE
 from tools.microbench import synth_states
 dev = _lib.require_gpu("cuda:0"); lib = _lib.load()
-_lib.set_option("train_fused", int(os.environ.get("AQG_TRAIN_FUSED", "1")))
+_lib.set_option("train_fused", int(os.environ.get("AQG_TRAIN_FUSED", "2")))
 model = GNNNetwork().to(dev); tr = GNNTrainer(model, max_batch=BATCH_SIZE)
 n = BATCH_SIZE * 50
 st = synth_states(n); A = model.policy_output_size
@@ -37,7 +37,14 @@ names[7] = ("heads inside the fused kernel", ["wait for pooled g", "hidden layer
 names[8] = ("train_board (fused)", ["loads + graph", "layer 1 + aggregate", "layer-2 mfma", "acc->LDS, aggregate 2", "layer-3 mfma", "aggregate 3 + pool", "heads (all)",
                                     "bwd3: mask, dP, aggregate", "bwd3: weight gradient", "bwd2: dgrad mfma", "bwd2: mask, dP, aggregate", "bwd2: weight gradient",
                                     "bwd1: dgrad mfma", "bwd1: mask, dP, aggregate", "bwd1: weight gradient"])
-if os.environ.get("AQG_TRAIN_FUSED", "1") == "1":
+names[9] = ("train_board_split (fused, fp16 split MFMA)", ["loads + board tables", "A_hat fragments + layer-1 linear", "layer 1: aggregation T+R, stores", "layer-2 linear",
+                                                            "layer 2: aggregation T+R, stores", "layer-3 linear + aggregation R + pool", "heads (all)",
+                                                            "bwd3: dP, aggregation T+R, stores", "bwd3: weight gradient", "bwd2: data gradient + mask", "bwd2: aggregation T+R, stores",
+                                                            "bwd2: weight gradient", "bwd1: data gradient + mask", "bwd1: aggregation R + weight gradient"])
+fused = os.environ.get("AQG_TRAIN_FUSED", "2")
+if fused == "2":
+    names = {k: v for k, v in names.items() if k in (6, 7, 9)}
+elif fused == "1":
     names = {k: v for k, v in names.items() if k in (6, 7, 8)}
 else:
     names = {k: v for k, v in names.items() if k < 7}

@@ -16,12 +16,13 @@ A = model.policy_output_size
 pi = torch.rand((n, A), device=dev); pi = pi / pi.sum(1, keepdim=True)
 z = torch.randint(-1, 2, (n,), device=dev).float()
 b = slice(0, BATCH_SIZE)
-for fused in (0, 1):
+for fused in (0, 1, 2):
     _lib.set_option("train_fused", fused)
     order = torch.randperm(n, device=dev)
     tr.run_epoch(st, pi, z, order[:BATCH_SIZE * 10]); torch.cuda.synchronize()
     t0 = time.perf_counter(); s = tr.run_epoch(st, pi, z, order); torch.cuda.synchronize(); t1 = time.perf_counter()
     print(f"train_fused={fused}: run_epoch {(t1 - t0) / 400 * 1e3:.4f} ms/step  ({n / (t1 - t0):.0f} positions/s)  loss sums {s.tolist()}")
+print("fallbacks:", _lib.load().aqg_gcn_train_fallbacks(0))
 for _ in range(5): tr.step(st[b], pi[b], z[b])
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(200): tr.step(st[b], pi[b], z[b])
