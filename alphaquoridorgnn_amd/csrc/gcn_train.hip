@@ -1255,9 +1255,11 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
         store_plane_tile(nt, oT, true);
         park_tile(nt, oR, msk[0]);
     });
+    TS(9, 14)
     park_store(h1);
     split_w();                                                          // W2 fragments
     request_w(W3);
+    TS(9, 15)
     __syncthreads();                                                    // planes of H1 complete
     TS(9, 2)
     // ---- layer 2
@@ -1317,12 +1319,25 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
     };
     TS(9, 5)
     // ---- heads, losses, head gradients (its first barrier publishes gs)
+#ifdef AQG_HEADS_INLINE      // developer A/B (tools/ab_train.sh): the heads inlined into this body
+    heads_board<8>(hsm, b, nullptr, hpm, pi_all, z_all, order, first, A, B, hp, hv, lg, pol, vp, val, loss, dhp, dhv, nullptr);
+#else
     heads_board_call((unsigned int)(size_t)(HeadsSmemLds*)&hsm, b, (gcf)hpm.p[0], (gcf)hpm.p[1], (gcf)hpm.p[2], (gcf)hpm.p[3], (gcf)hpm.p[4], (gcf)hpm.p[5],
                      (gcf)hpm.p[6], (gcf)hpm.p[7], (gcf)pi_all, (gcf)z_all, (const __attribute__((address_space(1))) int64_t*)order, first, A, B,
                      (gf)hp, (gf)hv, (gf)lg, (gf)pol, (gf)vp, (gf)val, (gf)loss, (gf)dhp, (gf)dhv);
+#endif
     TS(9, 6)
-    request_wt(W3);                                                     // (behind the heads: they hold ~100 weight registers of their own)
-    request_h(h2);
+    {
+        // (requested BEHIND the call: hoisted above it -- which the compiler does unless the base pointers pass through this empty
+        //  asm statement -- the 56 registers would be loaded, waited for, spilled around the call and reloaded)
+        const float* W3b = W3;
+        const float* h2b = h2;
+#ifndef AQG_ABL_LAUNDER
+        asm volatile("" : "+s"(W3b), "+s"(h2b));
+#endif
+        request_wt(W3b);
+        request_h(h2b);
+    }
     // ---- backward.  dg = hsm.dgv; scaled by a power of two s with max |dg| s in [128, 256)
     float dgs, inv_s;
     {
@@ -1363,23 +1378,23 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
                 split_tile(oR, nt, ah, al);
             });
     };
-    auto weight_grad = [&](float* __restrict__ pdW) {                   // dW_l[all j][this wave's k]: A = FR (all waves), B = parked H_{l-1}
+    auto weight_grad = [&](float* __restrict__ pdW) {                   // dW_l[all j][this wave's k]: A = parked H_{l-1}, B = FR (all waves)
 #pragma unroll
         for (int kb = 0; kb < 3; ++kb) mfma_fence(hl[kb]);              // (loaded, not computed: harmless)
 #pragma unroll
         for (int jt = 0; jt < 8; ++jt) {
+            // the TRANSPOSED tile dW^T[k][j] = sum_n H[n][k] dZ[n][j]: lane = row j = 16 jt + c of dW, registers = 4 consecutive
+            // columns k = 16 w + 4 q + r -- one 16-byte store per tile and lane (the other operand order needs four 4-byte ones)
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 3; ++kb) {
-                const u32x4 ah = *reinterpret_cast<const u32x4*>(&sm.FR[jt][kb][0][lane][0]);
-                const u32x4 al = *reinterpret_cast<const u32x4*>(&sm.FR[jt][kb][1][lane][0]);
-                o = mfma_f16(al, hh[kb], o);
-                o = mfma_f16(ah, hl[kb], o);
-                o = mfma_f16(ah, hh[kb], o);
+                const u32x4 zh_ = *reinterpret_cast<const u32x4*>(&sm.FR[jt][kb][0][lane][0]);
+                const u32x4 zl_ = *reinterpret_cast<const u32x4*>(&sm.FR[jt][kb][1][lane][0]);
+                o = mfma_f16(hl[kb], zh_, o);
+                o = mfma_f16(hh[kb], zl_, o);
+                o = mfma_f16(hh[kb], zh_, o);
             }
-            float* dst = pdW + (size_t)b * TH * TH + (size_t)(16 * jt + 4 * q) * TH + col;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(size_t)r * TH] = o[r] * inv_s;
+            st4(pdW + (size_t)b * TH * TH + (size_t)(16 * jt + c) * TH + 16 * wave + 4 * q, o * inv_s);
         }
     };
     // layer 3: dP3 = dg / V on the nodes whose H3 is positive

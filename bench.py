@@ -434,17 +434,30 @@ def main():
         train_ms = (time.time() - t1) / nsteps * 1e3
         step_ms = time_ms(lambda: trainer.step(tb[:BATCH_SIZE], tpi[:BATCH_SIZE], tz[:BATCH_SIZE]), 50, warmup=5)
         tflops = BATCH_SIZE * TRAIN_FLOP_PER_POSITION / (train_ms * 1e-3) / 1e12
-        train_leg = {"workload": "train_network.py epoch on the GNN: forward + CE(softmaxed policy) + MSE + backward + Adam, fp32, batch 128, "
+        fallbacks = int(_lib.load().aqg_gcn_train_fallbacks(1))
+        _lib.set_option("train_fused", 1)                         # the exact-f32 form of the same step (last round's default), for the record
+        trainer.run_epoch(tb, tpi, tz, order[:BATCH_SIZE * 10])
+        torch.cuda.synchronize()
+        t1 = time.time()
+        trainer.run_epoch(tb, tpi, tz, order)
+        torch.cuda.synchronize()
+        train_ms_f32 = (time.time() - t1) / nsteps * 1e3
+        _lib.set_option("train_fused", 2)
+        train_leg = {"workload": "train_network.py epoch on the GNN: forward + CE(softmaxed policy) + MSE + backward + Adam, f32 data, batch 128, "
                                  f"{nsteps} steps in one aqg_gcn_train_steps call (shuffle applied once per epoch)",
                      "ms_per_step": train_ms, "positions_per_s": BATCH_SIZE / (train_ms * 1e-3), "ms_per_step_single_calls": step_ms,
+                     "ms_per_step_f32_input_mfma_form": train_ms_f32, "positions_redone_in_f32": fallbacks,
                      "launches_per_step": 2,
-                     "roofline": {"kernel": "train_board_kernel<9> (one workgroup per position: forward + heads + backward, f32 MFMA 16x16x4) + train_final_kernel", "bound": "mfma", "achieved": tflops,
-                                  "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": tflops * 1e12 / PEAK_F32_MFMA,
+                     "roofline": {"kernel": "train_board_split_kernel (one workgroup per position: forward + heads + backward, every contraction "
+                                            "on v_mfma_f32_16x16x32_f16 in hi/lo split precision) + train_final_kernel", "bound": "mfma", "achieved": tflops,
+                                  "peak": PEAK_F16_MFMA / 3 / 1e12, "unit": "TFLOP/s", "frac": tflops * 1e12 / (PEAK_F16_MFMA / 3),
+                                  "frac_vs_f32_input_mfma_peak": tflops * 1e12 / PEAK_F32_MFMA,
                                   "flop_per_position": TRAIN_FLOP_PER_POSITION,
-                                  "note": "2.2 GFLOP per step; one 8-wave workgroup per position keeps every activation on its CU, so batch 128 "
-                                          "occupies 128 of the 256 CUs: the f32 matrix pipe of those CUs is busy ~48 % of the kernel "
-                                          "(profiles/r02_train_step_phase_stamps.log), i.e. the reachable roof at this batch size is half the "
-                                          "quoted peak"}}
+                                  "note": "2.2 GFLOP per step (algorithmic f32 FLOP; three fp16 products per f32 product on the pipe); one 8-wave "
+                                          "workgroup per position keeps every activation on its CU, so batch 128 occupies 128 of the 256 CUs and the "
+                                          "step is one position's dependent chain: ~720 MFMAs per wave (23 k of the ~105 k cycles of the kernel at two "
+                                          "waves per SIMD), the heads, 14 barriers (in-kernel stamps: profiles/r03_train_step_phase_stamps.log) -- "
+                                          "latency, not the matrix pipe, bounds it"}}
         del trainer, tr_model
 
     large = None

@@ -40,7 +40,8 @@ names[8] = ("train_board (fused)", ["loads + graph", "layer 1 + aggregate", "lay
 names[9] = ("train_board_split (fused, fp16 split MFMA)", ["loads + board tables", "A_hat fragments + layer-1 linear", "layer 1: aggregation T+R, stores", "layer-2 linear",
                                                             "layer 2: aggregation T+R, stores", "layer-3 linear + aggregation R + pool", "heads (all)",
                                                             "bwd3: dP, aggregation T+R, stores", "bwd3: weight gradient", "bwd2: data gradient + mask", "bwd2: aggregation T+R, stores",
-                                                            "bwd2: weight gradient", "bwd1: data gradient + mask", "bwd1: aggregation R + weight gradient"])
+                                                            "bwd2: weight gradient", "bwd1: data gradient + mask", "bwd1: aggregation R + weight gradient",
+                                                            "(wave 0) layer 1: aggregation + epilogues", "(wave 0) layer 1: park, W2 split"])
 fused = os.environ.get("AQG_TRAIN_FUSED", "2")
 if fused == "2":
     names = {k: v for k, v in names.items() if k in (6, 7, 9)}
