@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_kernel(const
 #define AQG_PREFETCH 0
 #endif
 // timing-only ablations (tools/ab_trunk.py; wrong results by construction, never shipped): AQG_ABL_BAR drops the per-board
-// barriers, AQG_ABL_SETUP builds a workgroup's inputs for its first board only, AQG_ABL_EPI drops the plane stores of the
+// barriers, AQG_ABL_SETUP builds a workgroup's inputs for its first board only (AQG_ABL_SETUP0: for none), AQG_ABL_EPI drops the plane stores of the
 // epilogues, AQG_ABL_LDSA the A-fragment reads of the linear maps, AQG_ABL_LIN / AQG_ABL_AGG the MFMAs
 #ifdef AQG_ABL_BAR
 #define AQG_BOARD_BARRIER() __builtin_amdgcn_sched_barrier(0)
@@ -1348,7 +1348,8 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
         u32x4 zh[JT][3], zl[JT][3];
         request_bias<JT>(out, rs, 0, toff, wave);                            // lands under the input build + barrier
         AQG_STAMP_AT(6)
-#ifdef AQG_ABL_SETUP
+#if defined(AQG_ABL_SETUP0)       // timing-only: no input build at all (what a workgroup would do if a board's fragments came ready-made)
+#elif defined(AQG_ABL_SETUP)
         if (first) build_inputs(par, hw, vw, hd, 3);
 #else
         if (!AQG_PREFETCH || first) build_inputs(par, hw, vw, hd, AQG_AF_AT == 0 ? 3 : 1);
@@ -1365,7 +1366,7 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
         load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights: land under the barrier
         __builtin_amdgcn_sched_barrier(0);
         phase_prio(2);
-#ifndef AQG_ABL_SETUP
+#if !defined(AQG_ABL_SETUP) && !defined(AQG_ABL_SETUP0)
         if (AQG_AF_AT == 1) build_inputs(par, hw, vw, hd, 2);
 #endif
         AQG_STAMP_AT(9)
