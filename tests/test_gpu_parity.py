@@ -931,6 +931,40 @@ def test_train_step_gradients_small_boards(dev, N):
             assert np.abs(gt.cpu().numpy().astype(np.float64) - r).max() <= 2e-5 * np.abs(r).max() + 1e-7, (N, fused, k)
 
 
+def test_train_split_step_falls_back_to_f32_out_of_fp16_range(dev):
+    """The split-precision step range-checks every value it is about to split; a position that meets |x| > 65504 is redone by the
+    f32 body inside the same launch.  Weights the reference's fp32 handles without blinking -- gcn_layers.1 scaled by 1e6 (its
+    entries alone leave fp16 range), the heads' first layers by 1e-6 so that losses and gradients stay ordinary -- must give, for
+    EVERY output, bit for bit what the f32 form gives, with every position counted as a fallback."""
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+    from alphaquoridorgnn_amd.train_network import GNNTrainer
+    from oracle import gnn as og
+    lib = _lib.load()
+    params = og.init_params(12)
+    params["gcn_layers.1.lin.weight"] = params["gcn_layers.1.lin.weight"] * np.float32(1e6)
+    for k in ("policy_head.0.weight", "value_head.0.weight"):
+        params[k] = params[k] * np.float32(1e-6)
+    recs, pi, z = _train_batch(40, 5)
+    outs = {}
+    for fused in (1, 2):
+        model = GNNNetwork()
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        model = model.to(dev)
+        _lib.set_option("train_fused", fused)
+        tr = GNNTrainer(model, max_batch=64)
+        lib.aqg_gcn_train_fallbacks(1)
+        pl, vl = tr.step(torch.from_numpy(recs), torch.from_numpy(pi), torch.from_numpy(z), update=False)
+        pol, val = tr.outputs(40)
+        outs[fused] = [float(pl), float(vl), pol.cpu().numpy().copy(), val.cpu().numpy().copy()] + [g.cpu().numpy().copy() for g in tr.grads]
+        assert lib.aqg_gcn_train_fallbacks(1) == (40 if fused == 2 else 0)
+    _lib.set_option("train_fused", TRAIN_FUSED_DEFAULT)
+    assert all(np.isfinite(x).all() for x in outs[2][2:])
+    assert max(np.abs(g).max() for g in outs[2][4:10]) > 0          # the trunk's gradients are not degenerate
+    for a, b in zip(outs[1], outs[2]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def test_train_adam_steps_vs_torch(dev):
     """Three Adam steps (LambdaLR factors 1.0, 0.5, 0.25 as at epochs 0 / 50 / 80) from the same start: parameters after
     each step against torch.optim.Adam driven by fp64 autograd.  Adam's update lr * m / (sqrt(v) + eps) is ~lr for EVERY
@@ -972,7 +1006,7 @@ def test_train_run_epoch_equals_single_steps(dev):
     board and, for the odd tile counts, on 5x5 (25 nodes = 2 row tiles) with its own parameter shapes."""
     from alphaquoridorgnn_amd.train_network import GNNTrainer
     from alphaquoridorgnn_amd.pv_network_gnn import GraphPolicyValueNetwork
-    for N, n, batch in ((9, 150, 64), (5, 70, 32)):
+    for N, n, batch, pre_shuffle in ((9, 150, 64, True), (9, 150, 64, False), (5, 70, 32, False)):
         A = N * N + 2 * (N - 1) ** 2
         recs, pi, z = _train_batch(n, 21, N=N)
         order = torch.from_numpy(np.random.RandomState(3).permutation(n))
@@ -982,7 +1016,7 @@ def test_train_run_epoch_equals_single_steps(dev):
         mb = GraphPolicyValueNetwork(policy_output_size=A, board_size=N).to(dev)
         mb.load_state_dict(ma.state_dict())
         ta, tb = GNNTrainer(ma, max_batch=batch), GNNTrainer(mb, max_batch=batch)
-        sums = ta.run_epoch(S, P, Z, order, lr=7e-4, pre_shuffle=(N == 9))     # both ways of applying the order
+        sums = ta.run_epoch(S, P, Z, order, lr=7e-4, pre_shuffle=pre_shuffle)  # both ways of applying the order
         ref = torch.zeros(2, device=dev)
         for i in range(0, n, batch):
             idx = order[i:i + batch].to(dev)
