@@ -1025,35 +1025,40 @@ template <class Post>
 __device__ __forceinline__ void linear_split_post(const unsigned char (&P)[2][PPLANE], const u32x4 (&Bh)[4], const u32x4 (&Bl)[4], int lane,
                                                   u32x4 (&zh)[3], u32x4 (&zl)[3], Post post) {
     const int c = lane & 15, q = lane >> 4;
-    u32x4 cur[2], nxt[2];
+    // The fragments of step s + AQG_TRAIN_FRAG_AHEAD are requested while step s multiplies (a ring of that many register pairs).
+    // One step ahead is enough: 2 / 3 / 5 steps measured 0.0568 / 0.0572 / 0.0613 ms per step against 0.0565 (tools/ab_train.sh) --
+    // the phase is not waiting for LDS.
+#ifndef AQG_TRAIN_FRAG_AHEAD
+#define AQG_TRAIN_FRAG_AHEAD 1
+#endif
+    constexpr int D = AQG_TRAIN_FRAG_AHEAD;
+    u32x4 ring[D + 1][2];
     auto frag_off = [&](int step) -> int {
         const int m = step >> 2, kb = step & 3;
         return plane_off(m < 5 ? 16 * m + c : 80, 4 * kb + q);
     };
-    {
-        const int o = frag_off(0);
-        cur[0] = *reinterpret_cast<const u32x4*>(&P[0][o]);
-        cur[1] = *reinterpret_cast<const u32x4*>(&P[1][o]);
-    }
+    auto request = [&](int step) {
+        const int o = frag_off(step);
+        ring[step % (D + 1)][0] = *reinterpret_cast<const u32x4*>(&P[0][o]);
+        ring[step % (D + 1)][1] = *reinterpret_cast<const u32x4*>(&P[1][o]);
+    };
+#pragma unroll
+    for (int i = 0; i < D; ++i) request(i);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, done = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int step = 0; step < 24; ++step) {
         const int m = step >> 2, kb = step & 3;
-        if (step < 23) {
-            const int o = frag_off(step + 1);
-            nxt[0] = *reinterpret_cast<const u32x4*>(&P[0][o]);
-            nxt[1] = *reinterpret_cast<const u32x4*>(&P[1][o]);
-        }
+        if (step + D < 24) request(step + D);
         __builtin_amdgcn_sched_barrier(0);                              // (keeps the 48 fragment reads from being hoisted in a body: 192 registers)
+        const u32x4 hi = ring[step % (D + 1)][0], lo = ring[step % (D + 1)][1];
         f32x4 a = kb == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc;
-        a = mfma_f16(cur[1], Bh[kb], a);
-        a = mfma_f16(cur[0], Bl[kb], a);
-        a = mfma_f16(cur[0], Bh[kb], a);
+        a = mfma_f16(lo, Bh[kb], a);
+        a = mfma_f16(hi, Bl[kb], a);
+        a = mfma_f16(hi, Bh[kb], a);
         acc = a;
         // the finished tile m - 1 is masked / checked and split under tile m's first MFMA group
         if (m > 0 && kb == 0) { post(m - 1, done); split_tile(done, m - 1, zh, zl); }
         __builtin_amdgcn_sched_barrier(0);
-        if (step < 23) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
         if (kb == 3) done = acc;
     }
     post(5, done);
