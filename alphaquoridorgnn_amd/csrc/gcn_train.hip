@@ -432,23 +432,11 @@ __device__ __forceinline__ void heads_board(HeadsSmem& sm, int b, const float* _
     float (&gs)[TH] = sm.gs; float (&hs)[TH] = sm.hs; float (&dhs)[TH] = sm.dhs; float (&dl)[256] = sm.dl;
     float (&red)[2][8][2] = sm.red;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, rg = lane >> 4, l = lane & 15;
-    const bool worker = t < 256;
     const float *Wp1 = Pm.p[0], *bp1 = Pm.p[1], *Wp2 = Pm.p[2], *bp2 = Pm.p[3], *Wv1 = Pm.p[4], *bv1 = Pm.p[5], *Wv2 = Pm.p[6], *bv2 = Pm.p[7];
     const size_t rec = record_of(order, first, b);
-    int flip = 0;                                 // two exchange rows, used alternately: one barrier per reduction
-    auto block_sum2 = [&](float& x, float& y) {
-        x = wave_sum(x); y = wave_sum(y);
-        if (lane == 0 && worker) { red[flip][wave][0] = x; red[flip][wave][1] = y; }
-        __syncthreads();
-        x = (red[flip][0][0] + red[flip][1][0]) + (red[flip][2][0] + red[flip][3][0]);      // waves 4.. hold zeros / -inf: not read
-        y = (red[flip][0][1] + red[flip][1][1]) + (red[flip][2][1] + red[flip][3][1]);
-        flip ^= 1;
-    };
-    auto block_max = [&](float v) { v = wave_max(v); if (lane == 0 && worker) red[flip][wave][0] = v; __syncthreads(); const float r = fmaxf(fmaxf(red[flip][0][0], red[flip][1][0]), fmaxf(red[flip][2][0], red[flip][3][0])); flip ^= 1; return r; };
     TS_DECL
     constexpr int HEADS_TS = NW == 4 ? 2 : 7;
     (void)HEADS_TS;
-    const bool on = t < A;
     constexpr int HG = TH / (4 * NW);                               // first-layer row groups per wave (4 rows each)
     constexpr int LG = 64 / NW;                                     // policy_head.2 row groups per wave: 64 groups = 256 rows >= A
     f32x4 w1a[HG], w1b[HG], w2[LG];
@@ -465,9 +453,17 @@ __device__ __forceinline__ void heads_board(HeadsSmem& sm, int b, const float* _
         const int a = 4 * (wave + NW * i) + rg;
         w2[i] = a < A ? ld4(Wp2 + (size_t)a * HH + 4 * l) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float tgt = on ? pi_all[rec * A + t] : 0.f;
-    const float zt = z_all[rec];
-    const float lb = on ? bp2[t] : 0.f, wv2 = Wv2[lane], bv = bv2[0];
+    // wave 0's inputs of the softmax / loss section, requested up front with everything else: targets and logit biases of its four
+    // logits per lane, the value head's second layer
+    float tgq[4], lbq[4], wv2q = 0.f, bvq = 0.f, ztq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int a = lane + 64 * j;
+        const bool ok = wave == 0 && a < A;
+        tgq[j] = ok ? pi_all[rec * A + a] : 0.f;
+        lbq[j] = ok ? bp2[a] : 0.f;
+    }
+    if (wave == 0) { wv2q = Wv2[lane]; bvq = bv2[0]; ztq = z_all[rec]; }
     if (g && t < TH) gs[t] = g[(size_t)b * TH + t];
     __syncthreads();
     TS(HEADS_TS, 0)
@@ -495,37 +491,71 @@ __device__ __forceinline__ void heads_board(HeadsSmem& sm, int b, const float* _
         }
     }
     __syncthreads();
-    const float lgt = on ? dl[t] + lb : -INFINITY;
-    __syncthreads();                                                 // everybody holds its logit before dl is overwritten
     TS(HEADS_TS, 2)
-    const float m = block_max(lgt);
-    const float e = on ? expf(lgt - m) : 0.f;
-    float se = e, tsum = tgt;
-    block_sum2(se, tsum);
-    const float p = e / se;                                      // first softmax (the network's own, pv_network_gnn.py:42)
-    const float e2 = on ? expf(p) : 0.f;                         // second softmax inside CrossEntropyLoss; p in [0,1]: no shift needed
-    float s2 = e2, vsum = wave == 0 ? wv2 * hs[HH + lane] : 0.f; // (the value head's 64-term dot product rides along)
-    block_sum2(s2, vsum);
-    const float qq = e2 / s2;
-    const float dpol = on ? (qq * tsum - tgt) / (float)B : 0.f;  // d(mean_b l_b) / d pol
-    float lp = on ? -tgt * (p - logf(s2)) : 0.f, dot = dpol * p;
-    block_sum2(lp, dot);
-    const float dlogit = on ? p * (dpol - dot) : 0.f;            // back through the first softmax
-    if (worker) dl[t] = dlogit;                                  // (zero for the rows A..255 of the padded row groups)
-    if (on) {
-        pol[(size_t)b * A + t] = p;
-        lg[(size_t)b * A + t] = dlogit;
-    }
-    const float v = tanhf(vsum + bv);
-    const float dv = v - zt;
-    const float dvp = (2.f * dv / (float)B) * (1.f - v * v);
-    if (t == 0) {
-        val[b] = v;
-        vp[b] = dvp;
-        loss[2 * b] = lp;
-        loss[2 * b + 1] = dv * dv;
+    // softmax, the reference's second softmax inside CrossEntropyLoss, both losses and the way back to the logits: ONE wavefront
+    // holds all A <= 256 logits (four per lane) and every reduction is a wave reduction -- no barrier until the results are out
+    // (four workgroup-wide reductions with a barrier each took 3.9 k cycles of the 12 k the heads need).
+    if (wave == 0) {
+        float lgv[4], tg[4], pv[4], dp[4];
+        float mxl = -INFINITY, ts = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a = lane + 64 * j;
+            const bool ok = a < A;
+            lgv[j] = ok ? dl[a] + lbq[j] : -INFINITY;
+            tg[j] = tgq[j];
+            mxl = fmaxf(mxl, lgv[j]);
+            ts += tg[j];
+        }
+        const float m = wave_max(mxl);
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pv[j] = lane + 64 * j < A ? expf(lgv[j] - m) : 0.f; se += pv[j]; }
+        se = wave_sum(se);
+        const float tsum = wave_sum(ts);
+        float s2 = 0.f, e2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pv[j] = pv[j] / se;                                  // first softmax (the network's own, pv_network_gnn.py:42)
+            e2[j] = lane + 64 * j < A ? expf(pv[j]) : 0.f;       // second softmax inside CrossEntropyLoss; p in [0,1]: no shift needed
+            s2 += e2[j];
+        }
+        s2 = wave_sum(s2);
+        const float ls2 = logf(s2);
+        float lp = 0.f, dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = lane + 64 * j < A;
+            dp[j] = ok ? ((e2[j] / s2) * tsum - tg[j]) / (float)B : 0.f;   // d(mean_b l_b) / d pol
+            lp += ok ? -tg[j] * (pv[j] - ls2) : 0.f;
+            dot += dp[j] * pv[j];
+        }
+        lp = wave_sum(lp);
+        dot = wave_sum(dot);
+        const float vsum = wave_sum(wv2q * hs[HH + lane]);       // the value head's 64-term dot product
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a = lane + 64 * j;
+            const float dlogit = a < A ? pv[j] * (dp[j] - dot) : 0.f;   // back through the first softmax
+            dl[a] = dlogit;                                             // (zero for the rows A..255 of the padded row groups)
+            if (a < A) {
+                pol[(size_t)b * A + a] = pv[j];
+                lg[(size_t)b * A + a] = dlogit;
+            }
+        }
+        const float v = tanhf(vsum + bvq);
+        const float dv = v - ztq;
+        const float dvp0 = (2.f * dv / (float)B) * (1.f - v * v);
+        if (lane == 0) {
+            red[0][0][0] = dvp0;
+            val[b] = v;
+            vp[b] = dvp0;
+            loss[2 * b] = lp;
+            loss[2 * b + 1] = dv * dv;
+        }
     }
     __syncthreads();
+    const float dvp = red[0][0][0];
     TS(HEADS_TS, 3)
     {   // d loss / d policy hidden layer: this quarter wave's rows of policy_head.2, transposed product
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
