@@ -1328,7 +1328,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
         // (FR, which the heads' scratch aliases, is first written in the backward pass)
         if (q == 0) { hsm.gs[col] = s; g_out[(size_t)b * TH + col] = s; }
     }
-    // the backward pass's own operands, requested under the heads: W3^T fragments and this wave's parked H2
+    // the backward pass's own operands: W_{l+1}^T fragments of the data gradients and this wave's parked H_{l-1} (requested a phase ahead)
     float wt[32];                                                       // W_l[32 kb + 8 q + e][col]: B fragments of the data gradients
     auto request_wt = [&](const float* __restrict__ W) {
 #pragma unroll
