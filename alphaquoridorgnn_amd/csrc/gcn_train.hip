@@ -1185,6 +1185,8 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
         }
     };
     request_w(W2);
+    // (warming the heads' matrices into this XCD's L2 from here -- one load per 64-byte line, as the f32 body does -- measured 6 % SLOWER
+    //  for this body: 0.0607 against 0.0572 ms per step, tools/ab_train.sh)
     // ---- the board: features, open sides, deg^-1/2
     const uint8_t* rec = states72 + record_of(order, first, b) * STATE72;
     if (t < 96) {
