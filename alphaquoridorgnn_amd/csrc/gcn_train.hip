@@ -9,13 +9,16 @@
 //   backward  dP = dH' (.) [H' > 0];  db = colsum dP;  dZ = A_hat dP (A_hat symmetric);  dW = dZ^T H;  dH = dZ W
 //   update    torch.optim.Adam (lr, betas, eps; bias-corrected; no weight decay, no amsgrad)
 //
-// The batch is 128 positions (train_network.py:15) = 10,368 graph nodes and 2.2 GFLOP per step.  Every contraction over the
-// node rows runs on the f32 matrix pipe (v_mfma_f32_16x16x4_f32: exact f32 products, which the 2e-5 gradient parity against
-// fp64 autograd needs).  Two forms of the step (aqg_set_option("train_fused")):
+// The batch is 128 positions (train_network.py:15) = 10,368 graph nodes and 2.2 GFLOP per step.  Three forms of the step
+// (aqg_set_option("train_fused")), all within 2e-5 max|g| of fp64 autograd:
 //
-//   fused (default): train_board_kernel -- ONE 8-wave workgroup per position does forward, heads + losses and backward; only
-//     the per-board partial gradients leave the CU -- then train_final_kernel.
-//   six launches + final: two workgroups per board split the 128 feature columns (all 256 CUs busy at batch 128) and exchange
+//   2, split (default on 9x9): train_board_split_kernel -- ONE 8-wave workgroup per position does forward, heads + losses and
+//     backward with every contraction on the 16-bit matrix pipe in fp16 hi/lo split precision (split_mfma.hpp; three fp16 products
+//     per f32 product, f32 accumulation: fp32-equivalent), the neighbourhood aggregation included (banded A_hat blocks as MFMA
+//     operands).  A position whose values leave fp16 range is redone by the f32 body in the same launch.  Then train_final_kernel.
+//   1, fused f32: train_board_kernel -- the same one-workgroup-per-position structure on the f32-input matrix pipe
+//     (v_mfma_f32_16x16x4_f32: exact f32 products), aggregation as a VALU gather over LDS; the default on 3x3 / 5x5 / 7x7.
+//   0, six launches + final: two workgroups per board split the 128 feature columns (all 256 CUs busy at batch 128) and exchange
 //     full rows through memory between launches:
 //       fwd12   (board, column half)  features + graph from the record; layer 1 (K = 6, both halves redundantly), layer 2 half
 //       fwd3    (board, column half)  layer 3 half + the mean pool of that half
