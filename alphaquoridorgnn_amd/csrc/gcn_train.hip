@@ -1034,10 +1034,27 @@ static_assert(SPLIT_KERNEL_SMEM <= 160 * 1024, "one workgroup per CU");
 __device__ unsigned int g_train_fallbacks = 0;
 constexpr int BWD_SCALE_LOG2 = 7;       // max |dg| s in [128, 256): dP3 = dg s / 81 <= 3.2, 2^14 of headroom, every lo half a normal fp16
 
-__device__ __forceinline__ void trk(float& m, const f32x4 v) {          // largest |x| seen (v_max3_f32 with |.| modifiers)
-    m = fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1])));
-    m = fmaxf(m, fmaxf(fabsf(v[2]), fabsf(v[3])));
+// Range guard: the largest |x| this lane has split.  (The bit-pattern form of the inference trunk -- one signed and one unsigned
+// integer maximum, one v_max3 per two values each, no canonicalising v_max per operand -- saves 400 of this body's 3,300 vector
+// instructions and is 7 % SLOWER here, 0.0610 against 0.0571 ms per step in a same-box A/B: -DAQG_INT_TRK, tools/ab_train.sh.)
+#ifdef AQG_INT_TRK
+struct Rng { int i = 0; unsigned int u = 0u; };
+__device__ __forceinline__ void trk(Rng& m, float a, float b) {
+    const int ia = __builtin_bit_cast(int, a), ib = __builtin_bit_cast(int, b);
+    m.i = max(max(ia, ib), m.i);
+    m.u = max(max((unsigned int)ia, (unsigned int)ib), m.u);
 }
+__device__ __forceinline__ bool out_of_fp16_range(const Rng& m) { return m.i > 0x477FE000 || m.u > 0xC77FE000u; }   // 65504.0f / -65504.0f
+// (through a scalar parameter: __builtin_bit_cast applied to a vector ELEMENT expression read element 0 for all four -- hipcc 7.2)
+__device__ __forceinline__ float relu1i(float x) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0)); }
+#else
+struct Rng { float m = 0.f; };
+__device__ __forceinline__ void trk(Rng& m, float a, float b) { m.m = fmaxf(m.m, fmaxf(fabsf(a), fabsf(b))); }
+__device__ __forceinline__ bool out_of_fp16_range(const Rng& m) { return !(m.m <= 65504.0f); }
+__device__ __forceinline__ float relu1i(float x) { return fmaxf(x, 0.f); }
+#endif
+__device__ __forceinline__ void trk(Rng& m, const f32x4 v) { trk(m, v[0], v[1]); trk(m, v[2], v[3]); }
+__device__ __forceinline__ f32x4 relu4i(const f32x4 v) { return f32x4{relu1i(v[0]), relu1i(v[1]), relu1i(v[2]), relu1i(v[3])}; }
 __device__ __forceinline__ void mfma_fence(u32x4& a) { asm volatile("s_nop 3" : "+v"(a)); }
 // tile m of a [nodes][16] accumulator image -> dwords 2 (m & 1), + 1 of k block m >> 1 of its hi / lo node-contraction fragments
 __device__ __forceinline__ void split_tile(const f32x4 z, int m, u32x4 (&zh)[3], u32x4 (&zl)[3]) {
@@ -1163,7 +1180,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), q = lane >> 4, c = lane & 15;
     const int col = 16 * wave + c;
     const float *W1 = tp.p[0], *b1 = tp.p[1], *W2 = tp.p[2], *b2 = tp.p[3], *W3 = tp.p[4], *b3 = tp.p[5];
-    float mx = 0.f;                                                    // range guard: largest |x| this lane has split
+    Rng mx;                                                            // range guard over everything this lane splits
     TS_DECL
     // ---- loads that do not depend on the board: biases (both layouts), W1, W2 rows of this wave's columns
     const f32x4 bT1 = ld4(b1 + 16 * wave + 4 * q), bT2 = ld4(b2 + 16 * wave + 4 * q);
@@ -1271,7 +1288,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
     const int poff = (2 * wave + (q >> 1)) /* 16-byte slot of features 16 w + 4 q .. */, pbyte = 8 * (q & 1);
     auto store_plane_tile = [&](int nt, f32x4 v, bool relu) {          // T form: lane = node c of tile nt, features 16 w + 4 q + r
         trk(mx, v);
-        if (relu) v = relu4(v);
+        if (relu) v = relu4i(v);
         if (nt < 5 || c == 0) plane_store4(sm.P, plane_off(16 * nt + c, poff) + pbyte, v);
     };
     unsigned int msk[3] = {0u, 0u, 0u};                                 // ReLU masks of the three layers: bit 4 nt + r, R layout
@@ -1280,7 +1297,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
         trk(mx, v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (v[r] > 0.f && live_row(nt, q, r)) m |= 1u << (4 * nt + r);
-        v = relu4(v);
+        v = relu4i(v);
         split_tile(v, nt, hh, hl);
     };
     auto park_store = [&](float* __restrict__ hpark) {
@@ -1345,7 +1362,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const float a0 = wt[8 * kb + 2 * p], a1 = wt[8 * kb + 2 * p + 1];
-                mx = fmaxf(mx, fmaxf(fabsf(a0), fabsf(a1)));
+                trk(mx, a0, a1);
                 Bh[kb][p] = cvt_pk_f16(a0, a1);
                 Bl[kb][p] = lo_pair(Bh[kb][p], a0, a1);
             }
@@ -1447,7 +1464,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
             for (int r = 0; r < 4; ++r) { v[r] = ((msk[2] >> (4 * nt + r)) & 1u) ? dgs : 0.f; sdb += v[r]; }
             split_tile(v, nt, zh, zl);
         }
-        mx = fmaxf(mx, fabsf(dgs));
+        trk(mx, dgs, dgs);
         store_db(sdb, 2);
 #pragma unroll
         for (int kb = 0; kb < 3; ++kb) mfma_fence(zl[kb]);
@@ -1521,7 +1538,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
         }
         TS(9, 13)
     }
-    return !__syncthreads_or(!(mx <= 65504.0f));
+    return !__syncthreads_or(out_of_fp16_range(mx));
 }
 
 // option "train_fused" = 3 forces the fallback for every board (tests)
