@@ -20,6 +20,7 @@
 #define AQG_TRACE_TU gcn
 #include "aqg_common.hpp"
 #include "split_mfma.hpp"
+#include "../../include/aqgnn.h"
 #include <vector>
 
 namespace aqg {
@@ -670,11 +671,14 @@ constexpr int F16_MAX_BITS = 0x477FE000;      // 65504.0f
 // maximum exceeds 65504's pattern exactly when a value (or +inf, or a NaN with a clear sign bit) does.  As UNSIGNED integers -inf
 // and the NaNs with the sign bit set lie above everything else: 0 x (-inf) in an adjacency block gives such a NaN on this
 // hardware, and relu maps it to 0 without a trace.  Two v_max3 per four values each.
+__device__ __forceinline__ int float_bits(float x) { return __builtin_bit_cast(int, x); }
 __device__ __forceinline__ void track_range(const f32x4 v, int& imax, unsigned int& umax) {
 #ifdef AQG_NO_RANGE_GUARD      // timing-only build (tools/ab_trunk.py): what the guard costs
     return;
 #endif
-    const int i0 = __builtin_bit_cast(int, v[0]), i1 = __builtin_bit_cast(int, v[1]), i2 = __builtin_bit_cast(int, v[2]), i3 = __builtin_bit_cast(int, v[3]);
+    // (through scalar parameters: __builtin_bit_cast applied to a vector ELEMENT expression -- bit_cast(int, v[1]) -- read element 0
+    //  for every index with hipcc 7.2, and the guard watched one value in four; tools/range_guard_probe.py pins the fixed form)
+    const int i0 = float_bits(v[0]), i1 = float_bits(v[1]), i2 = float_bits(v[2]), i3 = float_bits(v[3]);
     imax = max(max(i0, i1), imax);
     imax = max(max(i2, i3), imax);
     umax = max(max((unsigned int)i0, (unsigned int)i1), umax);
@@ -799,7 +803,7 @@ __device__ __forceinline__ void request_bias(f32x4 (&out)[6][JT], __amdgpu_buffe
 // The blocks of a node tile are consecutive (a dependent 16x16x32 chain issues at the full rate), so tile nt is complete while
 // tile nt + 1 is still on the matrix pipe: its relu / split / stores are vector and LDS work issued under those MFMAs.
 // (No plane byte is read here: the caller has passed the barrier behind the linear map, the stores are free to go.)
-template <int JT, bool LAST, class SM>
+template <int JT, bool LAST, bool TRACK = true, class SM>
 __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)[AF_BLOCKS][64][4], u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], f32x4 (&out)[6][JT], int wave, int lane,
                                                 const int (&toff)[3], __amdgpu_buffer_rsrc_t pooled_rs, int pooled_soff, int32_t* __restrict__ saturated,
                                                 float* pooled_lds = nullptr) {
@@ -825,7 +829,7 @@ __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)
         for (int j = 0; j < JT; ++j) {
             f32x4 v = out[nt][j];
             if (LAST) {
-                if (live) track_range(v, imax, umax);          // (only inf / NaN matter here: the pooled row is f32, the heads check its range)
+                if (TRACK && live) track_range(v, imax, umax); // (only inf / NaN matter here: the pooled row is f32, the heads check its range)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
                 if (live) sum[j] += v * dn;
@@ -834,7 +838,7 @@ __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)
                 // instead of becoming inf - inf = NaN that the next relu would silently turn into 0 -- and is REPORTED (imax):
                 // the host then serves the weight set with the exact-f32 kernels (and checks every set on calibration boards
                 // before it trusts this kernel at all, pv_network_gnn.packed_weights).
-                if (live) track_range(v, imax, umax);
+                if (TRACK && live) track_range(v, imax, umax);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = relu_sat16(v[e]);
                 if (live) store_split4(sm, plane_off(node, (col0 + 16 * j) >> 3) + ((2 * (col0 + 16 * j)) & 15), v);
@@ -859,7 +863,7 @@ __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)
         if (nt > 0 && (blk + 1 == AF_BLOCKS || af_nt(blk + 1) != nt)) epilogue(nt - 1);
     }
     epilogue(5);
-    report_saturation(LAST ? (imax >= 0x7F800000 || umax >= 0xFF800000u) : out_of_range(imax, umax), saturated);
+    if (TRACK) report_saturation(LAST ? (imax >= 0x7F800000 || umax >= 0xFF800000u) : out_of_range(imax, umax), saturated);
     if (LAST) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -900,7 +904,7 @@ __device__ __forceinline__ float lane_sel(uint64_t m, float a) {
 // rows of G' (lane = node; k-slots of q = 0 / 2 read the hi half, q = 1 the lo half, q = 3 meets zero weight slots), accumulated on
 // the bias rows.  The result already has the store layout (lane = node, 4 consecutive features): relu, fp16 split, plane stores.
 // 6 MFMAs per wave and feature tile where the linear-first form needed 6 + 20 (X0 W1, then the 128-wide banded aggregation).
-template <int JT, class SM>
+template <int JT, bool TRACK = true, class SM>
 __device__ __forceinline__ void layer1_store(SM& sm, const unsigned short (&G)[81][16], const u32x4 (&w1f)[JT], f32x4 (&out)[6][JT],
                                              int wave, int lane, int32_t* __restrict__ saturated) {
     const int c = lane & 15, q = lane >> 4;
@@ -921,13 +925,13 @@ __device__ __forceinline__ void layer1_store(SM& sm, const unsigned short (&G)[8
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             f32x4 v = out[nt][j];
-            if (live) track_range(v, imax, umax);
+            if (TRACK && live) track_range(v, imax, umax);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = relu_sat16(v[e]);
             if (live) store_split4(sm, plane_off(node, (col0 + 16 * j) >> 3) + ((2 * (col0 + 16 * j)) & 15), v);
         }
     }
-    report_saturation(out_of_range(imax, umax), saturated);
+    if (TRACK) report_saturation(out_of_range(imax, umax), saturated);
 }
 
 __device__ __forceinline__ uint32_t bit_of64(uint64_t m, int s) {             // bit s of a wave-uniform 64-bit mask
@@ -1233,7 +1237,10 @@ __device__ __forceinline__ void trunk_bias_offsets(uint64_t hw, uint64_t vw, int
 }
 
 // (hipcc's second launch-bound argument is waves per SIMD: workgroups per CU x waves per workgroup / 4 SIMDs)
-template <int JT, int WGS_PER_CU, bool FUSE = false>
+// TRACK = false: the caller has PROVEN that no value of this weight set can leave fp16 range on any record with at most
+// AQG_GNN_PROVEN_MAX_WALLS walls in hand (AQG_GNN_RANGE_PROVEN, include/aqgnn.h): the per-value range tracking of the epilogues (one
+// vector instruction per value: 4 % of the kernel) is dropped and each record's two wall counts are checked instead, on the scalar unit.
+template <int JT, int WGS_PER_CU, bool FUSE = false, bool TRACK = true>
 #ifdef AQG_TRUNK96
 // Experiment build: the 8-wave form capped at 96 vector registers (the compiler only honours a waves-per-SIMD request beyond what
 // the kernel's LDS allows when it cannot see the LDS size, hence dynamic LDS here): four trunk waves then leave 128 registers of a
@@ -1360,7 +1367,8 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
         AQG_STAMP_AT(0)
         phase_prio(1);
         // ---- layer 1: one MFMA per node tile on top of the bias rows, relu, planes
-        layer1_store<JT>(sm, sm.G16[par], w1f, out, wave, lane, saturated);
+        if (!TRACK && (((hd >> 8) & 0xffu) > AQG_GNN_PROVEN_MAX_WALLS || (hd >> 24) > AQG_GNN_PROVEN_MAX_WALLS)) report_saturation(true, saturated);
+        layer1_store<JT, TRACK>(sm, sm.G16[par], w1f, out, wave, lane, saturated);
         AQG_STAMP_AT(8)
         __builtin_amdgcn_sched_barrier(0);
         load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights: land under the barrier
@@ -1390,7 +1398,7 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
         AQG_BOARD_BARRIER();                                                    // every wave is done reading the planes
         AQG_STAMP_AT(13)
         phase_prio(4);
-        aggregate_store<JT, false>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, 0, saturated);
+        aggregate_store<JT, false, TRACK>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, 0, saturated);
         AQG_STAMP_AT(14)
         AQG_BOARD_BARRIER();
         AQG_STAMP_AT(3)
@@ -1413,14 +1421,14 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
             // the board's heads, right here: the plane image is dead once every wave is past its layer-3 linear map (the barrier)
             FusedHeadsScratch& hs = *reinterpret_cast<FusedHeadsScratch*>(&sm.P[0][0]);
             AQG_BOARD_BARRIER();
-            aggregate_store<JT, true>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, b * (HID * 4), saturated, hs.g);
+            aggregate_store<JT, true, TRACK>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, b * (HID * 4), saturated, hs.g);
             AQG_BOARD_BARRIER();
             const int tid = 64 * wave + lane;
             fused_heads_512(hs, rs, pk, A, tid, logits ? logits + (size_t)b * A : nullptr, policy ? policy + (size_t)b * A : nullptr,
                             value_pre ? value_pre + b : nullptr, value ? value + b : nullptr);
         } else {
             phase_prio(6);
-            aggregate_store<JT, true>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, b * (HID * 4), saturated);
+            aggregate_store<JT, true, TRACK>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, b * (HID * 4), saturated);
         }
         rec0 = nrec0; rec1 = nrec1;
         if (AQG_PREFETCH) par ^= 1;
@@ -2018,6 +2026,9 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
             hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2, true>), dim3(grid), dim3(512), AQG_TRUNK_DYN(8), st, states, fmt, B, packed, pooled, active, 0,
                                N * N + 2 * (N - 1) * (N - 1), logits, policy, value_pre, value, saturated);
             fused = true;
+        } else if ((flags & AQG_GNN_RANGE_PROVEN) && saturated) {
+            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2, false, false>), dim3(grid), dim3(512), AQG_TRUNK_DYN(8), st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),
+                               0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, saturated);
         } else {
             hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), AQG_TRUNK_DYN(8), st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),
                                0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, saturated);

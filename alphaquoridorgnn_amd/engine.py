@@ -201,7 +201,7 @@ class BatchedSelfPlay:
             ply += 1
             if ply >= limit or ply % check_every == 0:
                 c = self.counters()
-                if c["gnn_saturated"] and self.e.gnn_flags == 0:
+                if c["gnn_saturated"] and not (self.e.gnn_flags & _lib.GNN_EXACT_F32):
                     self._fall_back_to_exact_kernels()
                     ply = 0
                     continue
@@ -365,7 +365,7 @@ class MultiSetSelfPlay:
             ply += 1
             if ply >= limit or ply % check_every == 0:
                 c = self.counters()
-                if c["gnn_saturated"] and any(e.e.gnn_flags == 0 for e in self.sets):
+                if c["gnn_saturated"] and any(not (e.e.gnn_flags & _lib.GNN_EXACT_F32) for e in self.sets):
                     for _, eng in self._each():          # fp16-range guard: replay the generation on the exact f32 kernels
                         eng._fall_back_to_exact_kernels()
                     self._live = [True] * len(self.sets)

@@ -97,7 +97,29 @@ class GraphPolicyValueNetwork(nn.Module):
             for w in self._sat_words.values():
                 w.zero_()
             self._gnn_flags = self._calibrate(self._packed, device)
+            if self._gnn_flags == 0 and self._range_proven(host):
+                self._gnn_flags = _lib.GNN_RANGE_PROVEN
         return self._packed
+
+    def _range_proven(self, host):
+        """A static bound over ALL inputs (any board graph, any record with at most GNN_PROVEN_MAX_WALLS walls in hand per player) on
+        every value the split trunk holds as an fp16 pair (include/aqgnn.h, AQG_GNN_RANGE_PROVEN).  GCNConv is
+        P = A_hat (H W^T) + b with A_hat >= 0 and row sums sum_k A_hat[n][k] = (1/sqrt d_n) sum_{k in N[n]} 1/sqrt d_k <= sqrt d_n
+        <= sqrt 5, and H >= 0 after the ReLU, so  |Z_l| <= |W_l| h_{l-1},  |P_l|, H_l <= sqrt5 |Z_l|max-row + |b_l| =: h_l  with
+        h_0 = the feature maxima.  True for the weights, not for a sample of boards: when it holds, the kernels' per-value
+        range tracking is redundant and is switched off (the records' wall counts are still checked, on the scalar unit)."""
+        if self.board_size != 9:
+            return False
+        W1, b1, W2, b2, W3, b3 = (t.double().abs() for t in host[:6])
+        R = 5.0 ** 0.5
+        wmax = float(_lib.GNN_PROVEN_MAX_WALLS)
+        h = torch.tensor([1.0, wmax, 1.0, wmax, 1.0, 1.0], dtype=torch.float64)     # pv_network_cnn.py:88-114: one-hot, count, one-hot, count, bit, bit
+        worst = 0.0
+        for W, b in ((W1, b1), (W2, b2), (W3, b3)):
+            z = W @ h
+            h = R * z + b
+            worst = max(worst, R * float(z.max()), float(h.max()), float(W.max()))
+        return bool(np.isfinite(worst)) and 4.0 * worst < 65504.0
 
     def invalidate_packed(self):
         """Call after the parameters were changed behind torch's back (train_network.GNNTrainer updates them in place from
@@ -106,9 +128,10 @@ class GraphPolicyValueNetwork(nn.Module):
         self._packed_key = None
 
     def gnn_flags(self, device):
-        """Flags every GNN forward of this weight set must carry (0, or _lib.GNN_EXACT_F32 when the fp16-split kernels
-        cannot represent its activations: found on the calibration boards when the set is packed (_calibrate), or at run time
-        by the kernels' range guard (mark_saturated))."""
+        """Flags every GNN forward of this weight set must carry: 0; _lib.GNN_RANGE_PROVEN when a static bound shows that
+        nothing can leave fp16 range (_range_proven: the split kernels then skip their per-value range tracking); or
+        _lib.GNN_EXACT_F32 when the fp16-split kernels cannot represent its activations -- found on the calibration boards when
+        the set is packed (_calibrate), or at run time by the kernels' range guard (mark_saturated)."""
         self.packed_weights(device)
         return self._gnn_flags
 
@@ -200,7 +223,7 @@ class GraphPolicyValueNetwork(nn.Module):
                                                               _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value), flags,
                                                               _lib.ptr(word), _lib.stream_ptr(dev)),
                            "aqg_gcn_forward_boards_guarded")
-                if flags or not check_saturation or B == 0 or int(word.item()) == 0:
+                if (flags & _lib.GNN_EXACT_F32) or not check_saturation or B == 0 or int(word.item()) == 0:
                     break
                 self.mark_saturated(dev)          # outside fp16 range: repeat on the exact kernels, and stay there
         else:   # the reference's smaller boards (constants.py:5-20): plain kernels over a caller-owned workspace

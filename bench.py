@@ -303,10 +303,12 @@ def main():
     policy = torch.empty((B, 209), device=dev)
     value = torch.empty((B,), device=dev)
     pk = model.packed_weights(dev)
+    gnn_flags = model.gnn_flags(dev)          # what GraphPolicyValueNetwork.forward_states passes for this weight set (range guard: proven bound / tracking)
+    sat_word = model.saturation_word(dev)
 
     def fwd():
-        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(boards), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None,
-                                              _lib.ptr(value), 0, _lib.stream_ptr(dev)), "fwd")
+        _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(boards), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None,
+                                                      _lib.ptr(value), gnn_flags, _lib.ptr(sat_word), _lib.stream_ptr(dev)), "fwd")
     # every variant is timed three times in interleaved order and its best time kept: a single pass right after the pools
     # were freed under-reported the exact-f32 kernel by 3.4x in the round-1 driver run (4.96 M vs 17 M boards/s here)
     names = (("f32_mfma_exact", 1), ("f16_split_mm_8wave_x2", 6), ("f16_split_mm_4wave_x2", 5))
@@ -500,6 +502,9 @@ def main():
             "mean_plies_per_game": mean_plies,
             "positions_gathered_per_step": positions,
             "gnn_forward": {"workload": f"BASELINE configs[1]: pv_network_gnn forward, batch={B} synthetic boards (trunk + heads)",
+                            "fp16_range_guard": ("static bound over all inputs holds for this weight set: no per-value tracking (AQG_GNN_RANGE_PROVEN)"
+                                                 if gnn_flags & _lib.GNN_RANGE_PROVEN else "per-value range tracking in the epilogues"),
+                            "range_guard_word_after_run": int(sat_word.item()),
                             "boards_per_s": B / (fwd_ms * 1e-3), "ms": fwd_ms, "trunk_variants": variants,
                             "mfma_frac": B / (fwd_ms * 1e-3) * FWD_FLOP_PER_BOARD / (PEAK_F16_MFMA / SPLIT_TERMS),
                             "frac_vs_f32_input_mfma_peak": B / (fwd_ms * 1e-3) * FWD_FLOP_PER_BOARD / PEAK_F32_MFMA,

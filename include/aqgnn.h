@@ -116,6 +116,16 @@ int aqg_gcn_pack_weights_host(int board_size, const float* const* tensors_host, 
  *   host wrapper checks each weight set once against the exact kernels on calibration boards and sets this flag when they
  *   disagree (pv_network_gnn.GraphPolicyValueNetwork.packed_weights). */
 #define AQG_GNN_EXACT_F32 1
+/* AQG_GNN_RANGE_PROVEN (with a non-NULL `saturated` word, ignored together with AQG_GNN_EXACT_F32): the caller has PROVEN -- by a
+ * bound over ALL inputs whose two walls-in-hand counts are at most AQG_GNN_PROVEN_MAX_WALLS, not by sampling -- that no value the
+ * split trunk holds as an fp16 pair can leave fp16 range for this weight set.  The trunk then skips its per-value range tracking
+ * (one vector instruction per stored value, 4 % of the kernel) and checks each record's two wall counts against that maximum
+ * instead: a record beyond it raises the word exactly as an out-of-range value would.  The bound GraphPolicyValueNetwork uses
+ * (pv_network_gnn._range_proven): with R = sqrt(5) >= every row sum of A_hat and x_max = (1, W, 1, W, 1, 1) for W =
+ * AQG_GNN_PROVEN_MAX_WALLS,  z_1 = |W_1| x_max,  h_l = R z_l + |b_l|,  z_{l+1} = |W_{l+1}| h_l;  proven iff
+ * 4 max(R z_l, h_l, |W_l|) < 65504 (the factor 4 covers the kernel's internal scales c sqrt(deg) <= 2.1). */
+#define AQG_GNN_RANGE_PROVEN 2
+#define AQG_GNN_PROVEN_MAX_WALLS 16
 int aqg_gcn_forward_boards(int board_size, const void* states, int state_fmt, int B, const float* packed,
                            float* pooled, float* logits, float* policy, float* value_pre, float* value,
                            int flags, void* stream);

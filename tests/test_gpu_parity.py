@@ -159,7 +159,7 @@ def test_gnn_forward_boards_vs_fp64_oracle(dev, variant):
     from oracle import gnn as og
     _lib.set_option("trunk_variant", variant)
     model, params = _model(0)
-    assert model.gnn_flags(dev) == 0     # the range guard must not have swapped the kernels under test for the exact ones
+    assert not (model.gnn_flags(dev) & _lib.GNN_EXACT_F32)     # the range guard must not have swapped the kernels under test for the exact ones
     g = U.golden("walk_9x9.npz")
     sel = np.linspace(0, g["states"].shape[0] - 1, 300).astype(int)
     recs = g["states"][sel]
@@ -206,7 +206,7 @@ def test_gnn_forward_scaled_weights(dev, variant):
     big["gcn_layers.1.bias"] = np.linspace(-0.5, 0.5, 128).astype(np.float32)
     big["gcn_layers.2.bias"] = np.linspace(0.3, -0.3, 128).astype(np.float32)
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in big.items()})
-    assert model.gnn_flags(dev) == 0
+    assert not (model.gnn_flags(dev) & _lib.GNN_EXACT_F32)
     g = U.golden("walk_9x9.npz")
     recs = g["states"][5000:5064]
     ref = og.forward_states(big, recs)
@@ -245,7 +245,7 @@ def test_gnn_forward_many_boards_per_workgroup(dev, variant, B):
     model = model.to(dev).eval()
     _lib.set_option("trunk_variant", variant)
     try:
-        assert model.gnn_flags(dev) == 0
+        assert not (model.gnn_flags(dev) & _lib.GNN_EXACT_F32)
         g = U.golden("walk_9x9.npz")
         idx = np.random.RandomState(B + variant).randint(0, g["states"].shape[0], size=B)
         recs = torch.from_numpy(g["states"][idx]).to(dev)
@@ -319,7 +319,7 @@ def test_gnn_fp16_range_guard(dev):
     from alphaquoridorgnn_amd.engine import BatchedSelfPlay
     from oracle import gnn as og
     model, params = _model(3)
-    assert model.gnn_flags(dev) == 0
+    assert model.gnn_flags(dev) == _lib.GNN_RANGE_PROVEN          # initialisation-scale weights: the static bound holds, no tracking needed
     g = U.golden("walk_9x9.npz")
     recs = g["states"][7000:7048]
     for scale, want_flag in ((3.0, 0), (300.0, _lib.GNN_EXACT_F32)):
@@ -414,6 +414,105 @@ def test_gnn_runtime_saturation_signal(dev):
             assert eng.counters()["gnn_saturated"] == 0
             eng.search(crafted)
             assert eng.counters()["gnn_saturated"] == 1, which
+
+
+def test_gnn_range_guard_watches_every_feature(dev):
+    """The run-time fp16-range guard of the split kernels sees an excursion in ANY single feature column, whatever its position in a
+    lane's group of four (a compiler defect once made it watch one value in four while every test overflowed whole matrices):
+    one layer-1 output feature j beyond 65504 (positive), and one layer-2 linear-map output feature j beyond it on the negative
+    side, for j in every residue class mod 4 -- on the guarded C entry, for every split trunk form."""
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+    from oracle import gnn as og
+    lib = _lib.load()
+    g = U.golden("walk_9x9.npz")
+    normal = g["states"][[10, 400, 3000, 9000]].copy()
+    crafted = normal.copy()
+    crafted[:, 1] = 255
+    base = og.init_params(6)
+    word = torch.zeros((1,), dtype=torch.int32, device=dev)
+    pooled = torch.empty((4, 128), device=dev)
+    try:
+        for variant in (6, 5, 7):
+            _lib.set_option("trunk_variant", variant)
+            for kind in ("positive", "negative"):
+                for j in (0, 1, 2, 3, 37, 66, 127):
+                    p = {k: v.copy() for k, v in base.items()}
+                    if kind == "positive":
+                        p["gcn_layers.0.lin.weight"][j, 1] = 200.0           # layer-1 feature j ~ 2e5 at 255 walls in hand
+                    else:
+                        p["gcn_layers.0.lin.weight"][:, 1] = 20.0            # layer 1 in range (~ 2e4) ...
+                        p["gcn_layers.1.lin.weight"][j, :] = -0.05           # ... layer-2 output feature j ~ -1.3e5
+                    model = GNNNetwork()
+                    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+                    model = model.to(dev).eval()
+                    pk = model.packed_weights(dev)
+                    for recs, want in ((normal, 0), (crafted, 1)):
+                        word.zero_()
+                        d = torch.from_numpy(recs).to(dev)
+                        _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(d), 0, 4, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None,
+                                                                      0, _lib.ptr(word), _lib.stream_ptr(dev)), "guarded")
+                        assert int(word.item()) == want, (variant, kind, j, want)
+    finally:
+        _lib.set_option("trunk_variant", 3)
+
+
+def test_gnn_range_proven_path(dev):
+    """A weight set whose activations are bounded inside fp16 range for EVERY input with at most 16 walls in hand (a static bound
+    from the weights, pv_network_gnn._range_proven) is served by the trunk build without per-value range tracking: bit-identical
+    results to the tracking build on ordinary positions; a record outside the bound's premise (255 walls in hand) raises the
+    guard's word through the per-record wall-count check, and the module then returns the network's outputs from the exact kernels.
+    The bound itself: holds for initialisation-scale weights, fails -- as it must, being a bound -- once the trunk weights are x3."""
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+    from oracle import gnn as og
+    lib = _lib.load()
+    model, params = _model(9)
+    assert model.gnn_flags(dev) == _lib.GNN_RANGE_PROVEN
+    pk = model.packed_weights(dev)
+    g = U.golden("walk_9x9.npz")
+    recs = g["states"][500:1100].copy()
+    d = torch.from_numpy(recs).to(dev)
+    word = torch.zeros((1,), dtype=torch.int32, device=dev)
+    outs = []
+    for flags in (0, _lib.GNN_RANGE_PROVEN):
+        pooled = torch.empty((recs.shape[0], 128), device=dev)
+        policy = torch.empty((recs.shape[0], 209), device=dev)
+        _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(d), 0, recs.shape[0], _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None,
+                                                      None, flags, _lib.ptr(word), _lib.stream_ptr(dev)), "guarded")
+        outs.append((pooled, policy))
+    assert int(word.item()) == 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    crafted = recs[:4].copy()
+    crafted[1, 1] = 255                                   # the mover's walls in hand, one record of four
+    dc = torch.from_numpy(crafted).to(dev)
+    pooled = torch.empty((4, 128), device=dev)
+    _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(dc), 0, 4, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None,
+                                                  _lib.GNN_RANGE_PROVEN, _lib.ptr(word), _lib.stream_ptr(dev)), "guarded")
+    assert int(word.item()) == 1
+    crafted[1, 1] = 0
+    crafted[2, 3] = 17                                    # the enemy's count, just beyond the bound's premise
+    word.zero_()
+    _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(torch.from_numpy(crafted).to(dev)), 0, 4, _lib.ptr(pk), _lib.ptr(pooled), None, None, None,
+                                                  None, _lib.GNN_RANGE_PROVEN, _lib.ptr(word), _lib.stream_ptr(dev)), "guarded")
+    assert int(word.item()) == 1
+    crafted[2, 3] = 16                                    # at the premise: fine
+    word.zero_()
+    _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(torch.from_numpy(crafted).to(dev)), 0, 4, _lib.ptr(pk), _lib.ptr(pooled), None, None, None,
+                                                  None, _lib.GNN_RANGE_PROVEN, _lib.ptr(word), _lib.stream_ptr(dev)), "guarded")
+    assert int(word.item()) == 0
+    # the module on a record outside the premise: notices, switches, returns the network's outputs
+    crafted[1, 1] = 255
+    ref = og.forward_states(params, crafted)
+    _, _, logits, vpre = model.forward_states(torch.from_numpy(crafted).to(dev), want_logits=True)
+    assert model.gnn_flags(dev) == _lib.GNN_EXACT_F32
+    sc = max(float(np.abs(ref["logits"]).max()), 1.0)
+    np.testing.assert_allclose(logits.cpu().numpy(), ref["logits"], atol=2e-5 * sc, rtol=2e-4)
+    # the bound is a bound: x3 on the trunk weights and it no longer holds (the tracking build serves the set)
+    big = {k: (v * (3.0 if "gcn" in k and "weight" in k else 1.0)).astype(np.float32) for k, v in params.items()}
+    m3 = GNNNetwork()
+    m3.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in big.items()})
+    assert m3.to(dev).eval().gnn_flags(dev) == 0
 
 
 def test_gnn_small_boards_forward_and_selfplay(dev):
@@ -1456,7 +1555,7 @@ def test_generation_replays_on_exact_kernels_after_range_guard(dev):
     from alphaquoridorgnn_amd import _lib
     from alphaquoridorgnn_amd.engine import BatchedSelfPlay, MultiSetSelfPlay
     model, _ = _model(5)
-    assert model.gnn_flags(dev) == 0
+    assert not (model.gnn_flags(dev) & _lib.GNN_EXACT_F32)
     eng = BatchedSelfPlay(model, num_games=6, sims=6, seed=3)
     for _ in range(3):
         eng.move()

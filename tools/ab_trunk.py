@@ -39,13 +39,18 @@ for pth in paths:
     libs.append((L, out.to(dev)))
 res = {i: {} for i in range(len(libs))}
 stream = _lib.stream_ptr(dev)
+FLAGS = int(os.environ.get("AQG_AB_FLAGS", "0"))
+word = torch.zeros((1,), dtype=torch.int32, device=dev)
 for B in [int(x) for x in sys.argv[2].split(",")]:
     st = synth_states(B); pooled = torch.empty((B, 128), device=dev)
     ref = None
     for rnd in range(int(sys.argv[4])):
         for i, (L, pk) in enumerate(libs):
             def trunk():
-                assert L.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, 0, stream) == 0
+                if FLAGS:      # AQG_AB_FLAGS=2: the build without per-value range tracking (AQG_GNN_RANGE_PROVEN needs the guarded entry)
+                    assert L.aqg_gcn_forward_boards_guarded(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, FLAGS, _lib.ptr(word), stream) == 0
+                else:
+                    assert L.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, 0, stream) == 0
             for _ in range(10): trunk()
             n = 300 if B <= 4096 else 30
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
