@@ -20,8 +20,10 @@ st = synth_states(B)
 pooled = torch.empty((B, 128), device=dev)
 policy = torch.empty((B, 209), device=dev)
 value = torch.empty((B,), device=dev)
+flags = model.gnn_flags(dev)             # the module's own call: guarded entry, this weight set's flags (range guard: proven bound or tracking)
+word = model.saturation_word(dev)
 for _ in range(iters):
-    _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None,
-                                          _lib.ptr(value), 0, _lib.stream_ptr(dev)), "fwd")
+    _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None,
+                                                  _lib.ptr(value), flags, _lib.ptr(word), _lib.stream_ptr(dev)), "fwd")
 torch.cuda.synchronize()
 print("done", B, variant)
