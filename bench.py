@@ -509,7 +509,7 @@ def main():
                             "mfma_frac": B / (fwd_ms * 1e-3) * FWD_FLOP_PER_BOARD / (PEAK_F16_MFMA / SPLIT_TERMS),
                             "frac_vs_f32_input_mfma_peak": B / (fwd_ms * 1e-3) * FWD_FLOP_PER_BOARD / PEAK_F32_MFMA,
                             "hbm_frac_survey_formula": B / (fwd_ms * 1e-3) * HBM_BYTES_PER_BOARD / PEAK_HBM},
-            "roofline": {"kernel": "gcn_trunk_boards_mm_kernel<1,2> (GCN trunk: linear maps + aggregation on fp16 split MFMA)", "bound": "mfma",
+            "roofline": {"kernel": "gcn_trunk_boards_mm_kernel<1,2,false,TRACK> (GCN trunk: linear maps + aggregation on fp16 split MFMA; TRACK = false when the weight set's fp16 range is proven by a static bound, as for this run's weights)", "bound": "mfma",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / SPLIT_TERMS / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / (PEAK_F16_MFMA / SPLIT_TERMS),
                          "traffic": None,
