@@ -110,6 +110,8 @@ class GraphPolicyValueNetwork(nn.Module):
         range tracking is redundant and is switched off (the records' wall counts are still checked, on the scalar unit)."""
         if self.board_size != 9:
             return False
+        if not all(bool(torch.isfinite(t).all()) for t in host[:6]):
+            return False                                  # (Python's max() below would skip a NaN)
         W1, b1, W2, b2, W3, b3 = (t.double().abs() for t in host[:6])
         R = 5.0 ** 0.5
         wmax = float(_lib.GNN_PROVEN_MAX_WALLS)

@@ -360,3 +360,43 @@ def test_bench_cpu_baseline_workers():
     r = bench.cpu_baseline(8, 100.0, budget_s=2.0, workers=2)
     assert r["cores"] == 2 and r["kind"] == "port" and r["unit"] == "games/s"
     assert r["value"] > 0 and abs(r["sims_per_s"] - r["value"] * 100.0 * 8) <= 1e-6 * r["sims_per_s"]
+
+
+def test_static_fp16_range_bound_of_a_weight_set():
+    """pv_network_gnn._range_proven (what lets the split trunk drop its per-value range tracking, include/aqgnn.h
+    AQG_GNN_RANGE_PROVEN): a rigorous bound from the weights alone.  It must hold for initialisation-scale weights, fail once the
+    trunk weights are x3 or a bias is huge or anything is not finite, and -- being a bound -- dominate the activations the fp64
+    oracle actually produces on real positions (times the kernel's internal scale factor)."""
+    import torch
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork, STATE_DICT_KEYS
+    from oracle import gnn as og
+    params = og.init_params(4)
+    m = GNNNetwork()
+
+    def host(p):
+        return [torch.from_numpy(np.asarray(p[k], dtype=np.float32).copy()) for k in STATE_DICT_KEYS]
+
+    assert m._range_proven(host(params))
+    big = {k: (v * (3.0 if "gcn" in k and "weight" in k else 1.0)) for k, v in params.items()}
+    assert not m._range_proven(host(big))
+    hb = {k: v.copy() for k, v in params.items()}
+    hb["gcn_layers.1.bias"][5] = 3.0e4
+    assert not m._range_proven(host(hb))
+    nan = {k: v.copy() for k, v in params.items()}
+    nan["gcn_layers.2.lin.weight"][0, 0] = np.nan
+    assert not m._range_proven(host(nan))
+    # the bound dominates reality: the largest layer activation of the oracle on walk positions, with 10 walls in hand
+    recs = U.golden("walk_9x9.npz")["states"][::700]
+    p64 = {k: np.asarray(v, dtype=np.float64) for k, v in params.items()}
+    W = [np.abs(p64[f"gcn_layers.{l}.lin.weight"]) for l in range(3)]
+    b = [np.abs(p64[f"gcn_layers.{l}.bias"]) for l in range(3)]
+    h = np.array([1.0, 16.0, 1.0, 16.0, 1.0, 1.0])
+    bounds = []
+    for l in range(3):
+        h = np.sqrt(5.0) * (W[l] @ h) + b[l]
+        bounds.append(h.max())
+    for rec in recs:
+        x, e = og.node_features(rec).astype(np.float64), og.board_edges(rec)
+        for l in range(3):
+            x = np.maximum(og.gcn_conv(x, e, p64[f"gcn_layers.{l}.lin.weight"], p64[f"gcn_layers.{l}.bias"]), 0.0)
+            assert x.max() <= bounds[l]
