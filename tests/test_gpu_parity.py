@@ -1040,11 +1040,24 @@ def test_train_split_step_falls_back_to_f32_out_of_fp16_range(dev):
     from alphaquoridorgnn_amd.train_network import GNNTrainer
     from oracle import gnn as og
     lib = _lib.load()
-    params = og.init_params(12)
-    params["gcn_layers.1.lin.weight"] = params["gcn_layers.1.lin.weight"] * np.float32(1e6)
-    for k in ("policy_head.0.weight", "value_head.0.weight"):
-        params[k] = params[k] * np.float32(1e-6)
     recs, pi, z = _train_batch(40, 5)
+    for case in ("whole layer", "one output feature"):
+        params = og.init_params(12)
+        if case == "whole layer":
+            params["gcn_layers.1.lin.weight"] = params["gcn_layers.1.lin.weight"] * np.float32(1e6)
+            for k in ("policy_head.0.weight", "value_head.0.weight"):
+                params[k] = params[k] * np.float32(1e-6)
+        else:                                              # a single row (feature 5 of layer 2): its column alone leaves the range
+            params["gcn_layers.1.lin.weight"][5, :] *= np.float32(3e6)
+            params["gcn_layers.2.lin.weight"][:, 5] *= np.float32(1e-6)
+        _check_split_fallback(dev, params, recs, pi, z)
+
+
+def _check_split_fallback(dev, params, recs, pi, z):
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+    from alphaquoridorgnn_amd.train_network import GNNTrainer
+    lib = _lib.load()
     outs = {}
     for fused in (1, 2):
         model = GNNNetwork()
