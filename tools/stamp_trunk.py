@@ -17,13 +17,15 @@ dev = _lib.require_gpu("cuda:0"); lib = _lib.load()
 model = GNNNetwork().to(dev).eval(); pk = model.packed_weights(dev)
 B = int(os.environ.get("AQG_B", "65536"))
 st = synth_states(B)
+word = torch.zeros((1,), dtype=torch.int32, device=dev)
 names = ["setup", "L1a gather6", "L1b 6->128", "L2 mfma", "L2 stripe gather", "L3 mfma", "L3 gather+pool", "loop top", "wait vmcnt before L1b", "wait vmcnt before L3", "-", "-", "-", "-", "-", "-"]
 names5 = ["G' rows of layer 1 (+ fragments if built here), next-board index, barrier", "barrier after layer 1", "layer-2 linear (MFMA + split)", "barrier after layer-2 aggregation", "layer-3 linear (MFMA + split)", "layer-3 aggregation + pool + store", "record wait, decode, bias offsets, bias request", "loop top (w1f request)", "layer 1 (6 MFMAs on the bias rows, relu, plane stores)", "W2 fragment request (+ fragments if built here)", "next board's inputs if prefetched", "adjacency fragments if built after the layer-2 linear map", "W3 fragment request + next record", "barrier: planes read by everybody", "layer-2 aggregation + plane stores", "-"]
-for v, grid in ((6, 512), (5, 512)):
+for v, grid in ((6, 512),):
     _lib.set_option("trunk_variant", v); _lib.set_option("trunk_grid", grid)
     pooled = torch.zeros((B + 1, 128), device=dev)
     for _ in range(3):
-        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, 0, _lib.stream_ptr(dev)), "t")
+        _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None,
+                                                      int(os.environ.get("AQG_GNN_FLAGS", "2")), _lib.ptr(word), _lib.stream_ptr(dev)), "t")   # 2 = the build without per-value tracking
     torch.cuda.synchronize()
     raw = pooled[B].view(torch.int64)[:17].cpu().tolist()
     n = raw[16]; tot = sum(raw[:16])
