@@ -104,24 +104,27 @@ class GraphPolicyValueNetwork(nn.Module):
     def _range_proven(self, host):
         """A static bound over ALL inputs (any board graph, any record with at most GNN_PROVEN_MAX_WALLS walls in hand per player) on
         every value the split trunk holds as an fp16 pair (include/aqgnn.h, AQG_GNN_RANGE_PROVEN).  GCNConv is
-        P = A_hat (H W^T) + b with A_hat >= 0 and row sums sum_k A_hat[n][k] = (1/sqrt d_n) sum_{k in N[n]} 1/sqrt d_k <= sqrt d_n
-        <= sqrt 5, and H >= 0 after the ReLU, so  |Z_l| <= |W_l| h_{l-1},  |P_l|, H_l <= sqrt5 |Z_l|max-row + |b_l| =: h_l  with
-        h_0 = the feature maxima.  True for the weights, not for a sample of boards: when it holds, the kernels' per-value
+        P = A_hat (H W^T) + b with A_hat >= 0 and H >= 0 after the ReLU.  A row of A_hat sums to
+        1/d_n + sum_{k ~ n} 1/sqrt(d_n d_k) <= 1/d_n + (d_n - 1)/sqrt(2 d_n) <= R = 0.2 + 4/sqrt(10) = 1.465  (closed degrees d <= 5 on
+        the grid, and a neighbour of n has d_k >= 2: itself and n), so  |Z_l| <= |W_l| h_{l-1} =: z_l  and  |P_l|, H_l <= R z_l + |b_l|
+        =: h_l,  with h_0 = the feature maxima.  The kernel's own images are these times its internal scales: planes
+        CQ sqrt(d) H <= 2.10 h, linear-map outputs sqrt(d) Z <= 2.24 z, weights W / CQ <= 1.07 |W|: proven iff
+        2.3 max(z_l, h_l, |W_l|) < 65504.  True for the weights, not for a sample of boards: when it holds, the kernels' per-value
         range tracking is redundant and is switched off (the records' wall counts are still checked, on the scalar unit)."""
         if self.board_size != 9:
             return False
         if not all(bool(torch.isfinite(t).all()) for t in host[:6]):
             return False                                  # (Python's max() below would skip a NaN)
         W1, b1, W2, b2, W3, b3 = (t.double().abs() for t in host[:6])
-        R = 5.0 ** 0.5
+        R = 0.2 + 4.0 / 10.0 ** 0.5
         wmax = float(_lib.GNN_PROVEN_MAX_WALLS)
         h = torch.tensor([1.0, wmax, 1.0, wmax, 1.0, 1.0], dtype=torch.float64)     # pv_network_cnn.py:88-114: one-hot, count, one-hot, count, bit, bit
         worst = 0.0
         for W, b in ((W1, b1), (W2, b2), (W3, b3)):
             z = W @ h
             h = R * z + b
-            worst = max(worst, R * float(z.max()), float(h.max()), float(W.max()))
-        return bool(np.isfinite(worst)) and 4.0 * worst < 65504.0
+            worst = max(worst, float(z.max()), float(h.max()), float(W.max()))
+        return bool(np.isfinite(worst)) and 2.3 * worst < 65504.0
 
     def invalidate_packed(self):
         """Call after the parameters were changed behind torch's back (train_network.GNNTrainer updates them in place from

@@ -121,9 +121,10 @@ int aqg_gcn_pack_weights_host(int board_size, const float* const* tensors_host, 
  * split trunk holds as an fp16 pair can leave fp16 range for this weight set.  The trunk then skips its per-value range tracking
  * (one vector instruction per stored value, 4 % of the kernel) and checks each record's two wall counts against that maximum
  * instead: a record beyond it raises the word exactly as an out-of-range value would.  The bound GraphPolicyValueNetwork uses
- * (pv_network_gnn._range_proven): with R = sqrt(5) >= every row sum of A_hat and x_max = (1, W, 1, W, 1, 1) for W =
- * AQG_GNN_PROVEN_MAX_WALLS,  z_1 = |W_1| x_max,  h_l = R z_l + |b_l|,  z_{l+1} = |W_{l+1}| h_l;  proven iff
- * 4 max(R z_l, h_l, |W_l|) < 65504 (the factor 4 covers the kernel's internal scales c sqrt(deg) <= 2.1). */
+ * (pv_network_gnn._range_proven): with R = 0.2 + 4/sqrt(10) = 1.465 >= every row sum of A_hat on a wall-cut grid and x_max =
+ * (1, W, 1, W, 1, 1) for W = AQG_GNN_PROVEN_MAX_WALLS,  z_1 = |W_1| x_max,  h_l = R z_l + |b_l|,  z_{l+1} = |W_{l+1}| h_l;  proven
+ * iff 2.3 max(z_l, h_l, |W_l|) < 65504 (2.3 covers the kernel's internal scales: planes c sqrt(deg) H <= 2.10 h, linear-map
+ * outputs sqrt(deg) Z <= 2.24 z, weights W / c). */
 #define AQG_GNN_RANGE_PROVEN 2
 #define AQG_GNN_PROVEN_MAX_WALLS 16
 int aqg_gcn_forward_boards(int board_size, const void* states, int state_fmt, int B, const float* packed,

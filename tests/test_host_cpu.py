@@ -393,7 +393,7 @@ def test_static_fp16_range_bound_of_a_weight_set():
     h = np.array([1.0, 16.0, 1.0, 16.0, 1.0, 1.0])
     bounds = []
     for l in range(3):
-        h = np.sqrt(5.0) * (W[l] @ h) + b[l]
+        h = (0.2 + 4.0 / np.sqrt(10.0)) * (W[l] @ h) + b[l]
         bounds.append(h.max())
     for rec in recs:
         x, e = og.node_features(rec).astype(np.float64), og.board_edges(rec)
