@@ -624,6 +624,7 @@ struct alignas(16) TrunkSmemM {
     alignas(16) unsigned short G16[1 + AQG_PREFETCH][81][16];
     alignas(16) float Y[NWV][96];                      // per-wave scratch of the setup: X0[k][f] / sqrt(deg k) of the wave's feature
     alignas(16) unsigned short degv[NWV][NWV == 4 ? 3 : 2][32];   // per wave and block slot: fp16 CQ / deg of the 32 nodes of a k block
+    alignas(16) float dinvtab[8];                      // 1 / (81 CQ sqrt(deg)), deg = 1..5: the mean pool's weights, read by (deg - 1) * 4 (set once per workgroup)
 };
 static_assert(2 * sizeof(TrunkSmemM<8>) <= 160 * 1024, "two 8-wave workgroups per CU");
 
@@ -824,7 +825,9 @@ __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)
         const int node = 16 * nt + c;
         const bool live = (nt < 5) || (c == 0);                              // node < 81
         float dn = 0.f;
-        if (LAST) dn = dinv_of_dm(((unsigned)toff[nt >> 1] >> (9 + 16 * (nt & 1))) & 7u);    // deg - 1 sits above the row offset's 9 bits
+        // deg - 1 sits above the row offset's 9 bits (and the 16 q below them leave bits 7, 8 clear): bits 7..11 = (deg - 1) * 4, the byte
+        // offset into the 1 / sqrt(deg) table -- one v_bfe + one ds_read where the select chain took nine instructions per node tile
+        if (LAST) dn = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(sm.dinvtab) + (((unsigned)toff[nt >> 1] >> (7 + 16 * (nt & 1))) & 0x1Cu));
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             f32x4 v = out[nt][j];
@@ -832,7 +835,9 @@ __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)
                 if (TRACK && live) track_range(v, imax, umax); // (only inf / NaN matter here: the pooled row is f32, the heads check its range)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
+#ifndef AQG_ABL_POOL      // timing-only ablation (tools/ab_trunk.py): the mean pool's arithmetic removed
                 if (live) sum[j] += v * dn;
+#endif
             } else {
                 // relu, saturating at the largest finite fp16: an overflowing activation stays a (wrong) finite number
                 // instead of becoming inf - inf = NaN that the next relu would silently turn into 0 -- and is REPORTED (imax):
@@ -872,7 +877,11 @@ __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)
         for (int j = 0; j < JT; ++j) {
             f32x4 t;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = row16_sum(sum[j][e]) * (float)(1.0 / (81.0 * CQ));
+#ifdef AQG_ABL_POOL
+            for (int e = 0; e < 4; ++e) t[e] = sum[j][e];
+#else
+            for (int e = 0; e < 4; ++e) t[e] = row16_sum(sum[j][e]);             // (the table's entries carry the 1 / (81 CQ) of the mean)
+#endif
             // (buffer store off an SGPR descriptor + scalar row offset: no 64-bit address registers alive across the board loop)
             if (c == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), pooled_rs, (col0 + 16 * j) * 4, pooled_soff, 0);
             if (pooled_lds && c == 0) *reinterpret_cast<f32x4*>(pooled_lds + col0 + 16 * j) = t;
@@ -1321,6 +1330,7 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
         const int t0 = (int)threadIdx.x;
         for (int i = t0; i < (1 + AQG_PREFETCH) * 81 * 2; i += 64 * NWV)
             *reinterpret_cast<unsigned int*>(&sm.G16[0][0][0] + 16 * (i >> 1) + 6 + 8 * (i & 1)) = 0u;
+        if (t0 < 8) sm.dinvtab[t0] = dinv_of_dm((uint32_t)t0) * (float)(1.0 / (81.0 * CQ));   // (first read: the first board's layer 3, four barriers away)
     }
     u32x4 Bf[2][JT][4];
     const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
@@ -1469,6 +1479,7 @@ struct alignas(16) PairBoardSmem {
     alignas(16) unsigned char P[2][PPLANE];            // fp16 hi / lo planes of this board's activation image
     alignas(16) unsigned int AF[AF_BLOCKS][64][4];     // its adjacency fragments
     alignas(16) unsigned short G16[81][16];            // its layer-1 input rows
+    alignas(16) float dinvtab[8];                      // 1 / sqrt(deg), as in TrunkSmemM
 };
 struct alignas(16) TrunkPairSmem {
     PairBoardSmem bd[2];
@@ -1514,6 +1525,7 @@ __global__ __launch_bounds__(512, 2) void gcn_trunk_pairs_kernel(const void* __r
     // once per workgroup: the k-slots 6, 7 of the hi and lo halves of every G' row, which no board ever writes
     for (int i = (int)threadIdx.x; i < 2 * 81 * 2; i += 512)
         *reinterpret_cast<unsigned int*>(&sm.bd[i / 162].G16[0][0] + 16 * ((i % 162) >> 1) + 6 + 8 * (i & 1)) = 0u;
+    if (threadIdx.x < 16) sm.bd[threadIdx.x >> 3].dinvtab[threadIdx.x & 7] = dinv_of_dm((uint32_t)(threadIdx.x & 7)) * (float)(1.0 / (81.0 * CQ));
     u32x4 Bf[2][JT][4];
     const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pooled, 0, B * (HID * 4), 0x00020000);
