@@ -625,6 +625,7 @@ struct alignas(16) TrunkSmemM {
     alignas(16) float Y[NWV][96];                      // per-wave scratch of the setup: X0[k][f] / sqrt(deg k) of the wave's feature
     alignas(16) unsigned short degv[NWV][NWV == 4 ? 3 : 2][32];   // per wave and block slot: fp16 CQ / deg of the 32 nodes of a k block
     alignas(16) float dinvtab[8];                      // 1 / (81 CQ sqrt(deg)), deg = 1..5: the mean pool's weights, read by (deg - 1) * 4 (set once per workgroup)
+    alignas(16) float dinv1[8];                        // 1 / sqrt(deg): the layer-1 input rows' weights
 };
 static_assert(2 * sizeof(TrunkSmemM<8>) <= 160 * 1024, "two 8-wave workgroups per CU");
 
@@ -902,6 +903,11 @@ __device__ __forceinline__ uint32_t lane_bit(uint64_t m) {
     asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(uniform64(m)));
     return r;
 }
+template <int IMM> __device__ __forceinline__ uint32_t lane_val(uint64_t m) {     // bit `lane` of m ? IMM : 0  (IMM an inline constant)
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, 0, %2, %1" : "=v"(r) : "s"(uniform64(m)), "n"(IMM));
+    return r;
+}
 __device__ __forceinline__ float lane_sel(uint64_t m, float a) {
     float r;
     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(uniform64(m)));
@@ -1115,7 +1121,7 @@ __device__ __forceinline__ Planes degree_planes(const Open& op) {
 // other parity were last read a whole board ago: four barriers back).
 template <int NWV>
 __device__ __forceinline__ void trunk_build_inputs(unsigned short (&G16)[81][16], unsigned int (&AF)[AF_BLOCKS][64][4], float* __restrict__ Yw,
-                                               unsigned short (&degv)[NWV == 4 ? 3 : 2][32], int wave, uint64_t hw, uint64_t vw, uint32_t hd, int what) {
+                                               unsigned short (&degv)[NWV == 4 ? 3 : 2][32], const float (&dtab)[8], int wave, uint64_t hw, uint64_t vw, uint32_t hd, int what) {
 constexpr int N = 9, V = 81, NSLOT = NWV == 4 ? 3 : 2;
     const Open op = make_open<N>(hw, vw);
     const Planes pl = degree_planes(op);
@@ -1135,8 +1141,9 @@ constexpr int N = 9, V = 81, NSLOT = NWV == 4 ? 3 : 2;
                 else if (f == 4) m = shb;
                 else m = svb;
                 const int ln = fresh_lane(), l1 = min(ln, 16);
-                const float dnv0 = dinv_of_dm(lane_bit(pl.b0l) | (lane_bit(pl.b1l) << 1) | (lane_bit(pl.b2l) << 2));
-                const float dnv1 = dinv_of_dm(lane_bit(pl.b0h) | (lane_bit(pl.b1h) << 1) | (lane_bit(pl.b2h) << 2));
+                // 1 / sqrt(deg) of this lane's two nodes from the table: byte offset (deg - 1) * 4 assembled from the three degree bit planes
+                const float dnv0 = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(dtab) + (lane_val<4>(pl.b0l) | lane_val<8>(pl.b1l) | lane_val<16>(pl.b2l)));
+                const float dnv1 = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(dtab) + (lane_val<4>(pl.b0h) | lane_val<8>(pl.b1h) | lane_val<16>(pl.b2h)));
                 const float y0 = lane_sel(m.lo, sc) * dnv0, y1 = lane_sel(m.hi, sc) * dnv1;
                                 Yw[ln] = y0;
                 if (ln < 17) Yw[64 + ln] = y1;
@@ -1233,15 +1240,17 @@ constexpr int N = 9, V = 81, NSLOT = NWV == 4 ? 3 : 2;
 // pool's 1 / sqrt(deg)).  Straight from the record's degree bit planes: nothing here waits for a barrier.
 __device__ __forceinline__ void trunk_bias_offsets(uint64_t hw, uint64_t vw, int c, int q, int (&toff)[3]) {
     const Planes pl = degree_planes(make_open<9>(hw, vw));
+    const uint32_t qq = (uint32_t)(16 * q) * 0x00010001u;
+    // two node tiles per 32-bit plane word (nodes 32 p + c and 32 p + 16 + c are bits c and 16 + c): one shift + one mask per plane
+    // serves both tiles of a register
 #pragma unroll
-    for (int nt = 0; nt < 6; ++nt) {
-        const uint32_t w0 = nt < 4 ? (uint32_t)(pl.b0l >> (32 * (nt >> 1))) : (uint32_t)pl.b0h;
-        const uint32_t w1 = nt < 4 ? (uint32_t)(pl.b1l >> (32 * (nt >> 1))) : (uint32_t)pl.b1h;
-        const uint32_t w2 = nt < 4 ? (uint32_t)(pl.b2l >> (32 * (nt >> 1))) : (uint32_t)pl.b2h;
-        const int sft = (nt < 4 ? 16 * (nt & 1) : 16 * (nt - 4)) + c;
-        const int dm = (int)(((w0 >> sft) & 1u) | (((w1 >> sft) & 1u) << 1) | (((w2 >> sft) & 1u) << 2));
-        const int o = dm * (HID * 4) + 16 * q;
-        toff[nt >> 1] = (nt & 1) ? (toff[nt >> 1] | (o << 16)) : o;
+    for (int p = 0; p < 3; ++p) {
+        const uint32_t w0 = p < 2 ? (uint32_t)(pl.b0l >> (32 * p)) : (uint32_t)pl.b0h;
+        const uint32_t w1 = p < 2 ? (uint32_t)(pl.b1l >> (32 * p)) : (uint32_t)pl.b1h;
+        const uint32_t w2 = p < 2 ? (uint32_t)(pl.b2l >> (32 * p)) : (uint32_t)pl.b2h;
+        const uint32_t x0 = (w0 >> c) & 0x00010001u, x1 = (w1 >> c) & 0x00010001u, x2 = (w2 >> c) & 0x00010001u;
+        const uint32_t dm2 = x0 | (x1 << 1) | (x2 << 2);                 // deg - 1 of the even tile in bits 0..2, of the odd tile in bits 16..18
+        toff[p] = (int)((dm2 << 9) + qq);                                // (deg - 1) * HID * 4 + 16 q, twice
     }
 }
 
@@ -1330,7 +1339,8 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
         const int t0 = (int)threadIdx.x;
         for (int i = t0; i < (1 + AQG_PREFETCH) * 81 * 2; i += 64 * NWV)
             *reinterpret_cast<unsigned int*>(&sm.G16[0][0][0] + 16 * (i >> 1) + 6 + 8 * (i & 1)) = 0u;
-        if (t0 < 8) sm.dinvtab[t0] = dinv_of_dm((uint32_t)t0) * (float)(1.0 / (81.0 * CQ));   // (first read: the first board's layer 3, four barriers away)
+        if (t0 < 8) { sm.dinvtab[t0] = dinv_of_dm((uint32_t)t0) * (float)(1.0 / (81.0 * CQ)); sm.dinv1[t0] = dinv_of_dm((uint32_t)t0); }
+        __syncthreads();                                          // (dinv1 is read by the first board's input build)
     }
     u32x4 Bf[2][JT][4];
     const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
@@ -1338,7 +1348,7 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
 
     auto decode = [&](uint32_t r0, uint32_t r1, uint64_t& hw, uint64_t& vw, uint32_t& hd) { trunk_decode(fmt, r0, r1, hw, vw, hd); };
     auto build_inputs = [&](int par, uint64_t hw, uint64_t vw, uint32_t hd, int what) {
-        trunk_build_inputs<NWV>(sm.G16[par], sm.AF[par], sm.Y[wave], sm.degv[wave], wave, hw, vw, hd, what);
+        trunk_build_inputs<NWV>(sm.G16[par], sm.AF[par], sm.Y[wave], sm.degv[wave], sm.dinv1, wave, hw, vw, hd, what);
     };
 
     AQG_STAMP_DECL
@@ -1479,7 +1489,8 @@ struct alignas(16) PairBoardSmem {
     alignas(16) unsigned char P[2][PPLANE];            // fp16 hi / lo planes of this board's activation image
     alignas(16) unsigned int AF[AF_BLOCKS][64][4];     // its adjacency fragments
     alignas(16) unsigned short G16[81][16];            // its layer-1 input rows
-    alignas(16) float dinvtab[8];                      // 1 / sqrt(deg), as in TrunkSmemM
+    alignas(16) float dinvtab[8];                      // as in TrunkSmemM
+    alignas(16) float dinv1[8];
 };
 struct alignas(16) TrunkPairSmem {
     PairBoardSmem bd[2];
@@ -1525,7 +1536,11 @@ __global__ __launch_bounds__(512, 2) void gcn_trunk_pairs_kernel(const void* __r
     // once per workgroup: the k-slots 6, 7 of the hi and lo halves of every G' row, which no board ever writes
     for (int i = (int)threadIdx.x; i < 2 * 81 * 2; i += 512)
         *reinterpret_cast<unsigned int*>(&sm.bd[i / 162].G16[0][0] + 16 * ((i % 162) >> 1) + 6 + 8 * (i & 1)) = 0u;
-    if (threadIdx.x < 16) sm.bd[threadIdx.x >> 3].dinvtab[threadIdx.x & 7] = dinv_of_dm((uint32_t)(threadIdx.x & 7)) * (float)(1.0 / (81.0 * CQ));
+    if (threadIdx.x < 16) {
+        sm.bd[threadIdx.x >> 3].dinvtab[threadIdx.x & 7] = dinv_of_dm((uint32_t)(threadIdx.x & 7)) * (float)(1.0 / (81.0 * CQ));
+        sm.bd[threadIdx.x >> 3].dinv1[threadIdx.x & 7] = dinv_of_dm((uint32_t)(threadIdx.x & 7));
+    }
+    __syncthreads();
     u32x4 Bf[2][JT][4];
     const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pooled, 0, B * (HID * 4), 0x00020000);
@@ -1550,8 +1565,8 @@ __global__ __launch_bounds__(512, 2) void gcn_trunk_pairs_kernel(const void* __r
             trunk_bias_offsets(hw[d], vw[d], c, q, toff[d]);
             request_bias<JT>(out[d], rs, 0, toff[d], wave);                // lands under the input build + barrier
         }
-        if (live0) trunk_build_inputs<NWV>(sm.bd[0].G16, sm.bd[0].AF, sm.Y[wave], sm.degv[wave], wave, hw[0], vw[0], hd[0], 1);
-        if (live1) trunk_build_inputs<NWV>(sm.bd[1].G16, sm.bd[1].AF, sm.Y[wave], sm.degv[wave], wave, hw[1], vw[1], hd[1], 1);
+        if (live0) trunk_build_inputs<NWV>(sm.bd[0].G16, sm.bd[0].AF, sm.Y[wave], sm.degv[wave], sm.bd[0].dinv1, wave, hw[0], vw[0], hd[0], 1);
+        if (live1) trunk_build_inputs<NWV>(sm.bd[1].G16, sm.bd[1].AF, sm.Y[wave], sm.degv[wave], sm.bd[1].dinv1, wave, hw[1], vw[1], hd[1], 1);
         const int pn = next_pair(p + gridDim.x);
         __syncthreads();                      // both boards' G' rows are complete; the previous pair is done
         // ---- layer 1
@@ -1560,8 +1575,8 @@ __global__ __launch_bounds__(512, 2) void gcn_trunk_pairs_kernel(const void* __r
         __builtin_amdgcn_sched_barrier(0);
         load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights, once for the pair
         __builtin_amdgcn_sched_barrier(0);
-        if (live0) trunk_build_inputs<NWV>(sm.bd[0].G16, sm.bd[0].AF, sm.Y[wave], sm.degv[wave], wave, hw[0], vw[0], hd[0], 2);
-        if (live1) trunk_build_inputs<NWV>(sm.bd[1].G16, sm.bd[1].AF, sm.Y[wave], sm.degv[wave], wave, hw[1], vw[1], hd[1], 2);
+        if (live0) trunk_build_inputs<NWV>(sm.bd[0].G16, sm.bd[0].AF, sm.Y[wave], sm.degv[wave], sm.bd[0].dinv1, wave, hw[0], vw[0], hd[0], 2);
+        if (live1) trunk_build_inputs<NWV>(sm.bd[1].G16, sm.bd[1].AF, sm.Y[wave], sm.degv[wave], sm.bd[1].dinv1, wave, hw[1], vw[1], hd[1], 2);
         __syncthreads();
         // ---- layer 2
         if (live0) request_bias<JT>(out[0], rs, 1, toff[0], wave);
