@@ -637,6 +637,32 @@ __device__ __forceinline__ float row16_sum(float x) {     // sum over the 16 lan
     return x;
 }
 
+// The same for four values at once, as sixteen v_add_f32 with a DPP operand: the four chains are interleaved, so each add's DPP
+// source was written four instructions earlier (a DPP read needs two wait states behind the VALU write of its source; hipcc
+// pads nothing inside an asm statement).  hipcc turns the builtin form into v_mov_b32_dpp + packed adds: 24 instructions.
+__device__ __forceinline__ f32x4 row16_sum4(f32x4 v) {
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    return (f32x4){a, b, c, d};
+}
+
 // Weight fragments are fetched with buffer loads: one SGPR resource for the packed buffer, one shared VGPR (lane * 16)
 // and a scalar offset per load -- no 64-bit address VGPRs (they were the first thing the allocator spilled, and a
 // spilled address is reloaded behind an s_waitcnt vmcnt(0) that serialises the whole prefetch).
@@ -877,11 +903,10 @@ __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             f32x4 t;
-#pragma unroll
 #ifdef AQG_ABL_POOL
-            for (int e = 0; e < 4; ++e) t[e] = sum[j][e];
+            t = sum[j];
 #else
-            for (int e = 0; e < 4; ++e) t[e] = row16_sum(sum[j][e]);             // (the table's entries carry the 1 / (81 CQ) of the mean)
+            t = row16_sum4(sum[j]);                                              // (the table's entries carry the 1 / (81 CQ) of the mean)
 #endif
             // (buffer store off an SGPR descriptor + scalar row offset: no 64-bit address registers alive across the board loop)
             if (c == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), pooled_rs, (col0 + 16 * j) * 4, pooled_soff, 0);
