@@ -1239,15 +1239,16 @@ constexpr int N = 9, V = 81, NSLOT = NWV == 4 ? 3 : 2;
                 if (n < V) {
                     const int w = nt >> 1, sft = n & 31;                 // n >> 5 == nt >> 1: the word is wave-uniform
                     // window of row n of (A + I) around the diagonal: bit (k - n + 9), k = n-9 (U), n-1 (L), n, n+1 (R), n+9 (D)
-                    const uint32_t win = (1u << 9) | ((open_word(0, w) >> sft) & 1u) | (((open_word(2, w) >> sft) & 1u) << 8) |
-                                         (((open_word(3, w) >> sft) & 1u) << 10) | (((open_word(1, w) >> sft) & 1u) << 18);
-                    const int d0 = 32 * kb + 4 * q - n + 9;              // window bit of k-slot e = 0; e = 4 sits 16 higher
+                    // (kept four bits up: the four slots of a half then are bits s .. s + 3 of it for s = window position + 4, and a
+                    //  position left of the window (s < 0) or right of it (s > 31) reads zeros once s is clamped to 0..31 -- the low four
+                    //  bits and everything above bit 22 are clear)
+                    const uint32_t win4 = (1u << 13) | (((open_word(0, w) >> sft) & 1u) << 4) | (((open_word(2, w) >> sft) & 1u) << 12) |
+                                          (((open_word(3, w) >> sft) & 1u) << 14) | (((open_word(1, w) >> sft) & 1u) << 22);
+                    const int d0 = 32 * kb + 4 * q - n + 9 + 4;          // window bit of k-slot e = 0 (+ 4); e = 4 sits 16 higher
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const u32x2 dv = *reinterpret_cast<const u32x2*>(&degv[it][16 * h + 4 * q]);   // nodes 32 kb + 16 h + 4 q + 0..3
-                        const int d = d0 + 16 * h;
-                        uint32_t nib = (d >= 0) ? (win >> min(d, 31)) : (win << min(-d, 4));
-                        nib &= 0xFu;
+                        const uint32_t nib = (win4 >> (uint32_t)min(max(d0 + 16 * h, 0), 31)) & 0xFu;
                         const uint32_t t2 = nib | (nib << 15);           // b0 -> bit 0, b1 -> bit 16, b2 -> bit 2, b3 -> bit 18
                         fr[2 * h] = ((t2 & 0x00010001u) * 0xFFFFu) & dv[0];          // 0xFFFF in each selected half
                         fr[2 * h + 1] = (((t2 >> 2) & 0x00010001u) * 0xFFFFu) & dv[1];
