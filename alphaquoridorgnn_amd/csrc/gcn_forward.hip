@@ -1215,7 +1215,7 @@ constexpr int N = 9, V = 81, NSLOT = NWV == 4 ? 3 : 2;
             const int blk = slot_block(it);
             if (blk < AF_BLOCKS && lane < 32) {
                 const int kb = (AF_KB_PACK >> (2 * blk)) & 3;
-                const int l = fresh_lane();
+                const int l = lane;
                 const uint32_t deg = 1u + ((open_word(0, kb) >> l) & 1u) + ((open_word(1, kb) >> l) & 1u) +
                                      ((open_word(2, kb) >> l) & 1u) + ((open_word(3, kb) >> l) & 1u);
                 // fp16 of CQ / deg = 0.9375, 0.46875, 0.3125, 0.234375, 0.1875 (all exact)
@@ -1233,7 +1233,7 @@ constexpr int N = 9, V = 81, NSLOT = NWV == 4 ? 3 : 2;
             const int blk = slot_block(it);
             if (blk < AF_BLOCKS) {
                 const int kb = (AF_KB_PACK >> (2 * blk)) & 3, nt = (AF_NT_PACK >> (3 * blk)) & 7;
-                const int ln = fresh_lane();      // no per-slot lane constant is kept alive (spilled) across the loop
+                const int ln = lane;
                 const int n = 16 * nt + (ln & 15), q = ln >> 4;
                 u32x4 fr = (u32x4){0u, 0u, 0u, 0u};
                 if (n < V) {
@@ -1250,8 +1250,12 @@ constexpr int N = 9, V = 81, NSLOT = NWV == 4 ? 3 : 2;
                         const u32x2 dv = *reinterpret_cast<const u32x2*>(&degv[it][16 * h + 4 * q]);   // nodes 32 kb + 16 h + 4 q + 0..3
                         const uint32_t nib = (win4 >> (uint32_t)min(max(d0 + 16 * h, 0), 31)) & 0xFu;
                         const uint32_t t2 = nib | (nib << 15);           // b0 -> bit 0, b1 -> bit 16, b2 -> bit 2, b3 -> bit 18
-                        fr[2 * h] = ((t2 & 0x00010001u) * 0xFFFFu) & dv[0];          // 0xFFFF in each selected half
-                        fr[2 * h + 1] = (((t2 >> 2) & 0x00010001u) * 0xFFFFu) & dv[1];
+                        // a packed 16-bit multiply by the 0 / 1 of each half keeps or clears the half (v_pk_mul_lo_u16)
+                        // (scalars first: __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index -- hipcc 7.2, see track_range)
+                        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                        const uint32_t dv0 = dv[0], dv1 = dv[1], s0 = t2 & 0x00010001u, s1 = (t2 >> 2) & 0x00010001u;
+                        fr[2 * h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, s0) * __builtin_bit_cast(u16x2, dv0));
+                        fr[2 * h + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, s1) * __builtin_bit_cast(u16x2, dv1));
                     }
                 }
                 *reinterpret_cast<u32x4*>(&AF[blk][ln][0]) = fr;
