@@ -758,49 +758,67 @@ __device__ __forceinline__ void split_tile_piece(const f32x4 z, int m, int piece
 // U = Q W~ for this wave's columns: six 16-row tiles (tile 5 = row 80 repeated) x four 32-deep k blocks, A fragments
 // double-buffered from the planes, three fp16 terms per block (smallest first).  The fp16 split of tile m - 1 (six vector
 // instructions per feature tile) is issued between the MFMA groups of tile m: it costs no time of its own.
-template <int JT, class SM>
-__device__ __forceinline__ void linear_split(const SM& sm, const u32x4 (&Bf)[2][JT][4], int lane, u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3]) {
+// mid() is called in front of step AQG_BIAS_STEP: the kernel requests the aggregation's bias rows there (24 registers that need
+// not be alive through the first steps of the map -- room for a deeper fragment ring at the 128-register cap).
+#ifndef AQG_BIAS_STEP
+#define AQG_BIAS_STEP 0
+#endif
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+template <int JT, class SM, class Mid = NoMid>
+__device__ __forceinline__ void linear_split(const SM& sm, const u32x4 (&Bf)[2][JT][4], int lane, u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], Mid mid = Mid()) {
     const int c = lane & 15, q = lane >> 4;
-    u32x4 cur[2], nxt[2];
+    // the fragments of step s + AQG_LIN_AHEAD are requested while step s multiplies (a ring of that many register pairs).  One step
+    // ahead is enough with four waves per SIMD: 2 / 3 steps measured 48.0 / 45.4 M boards/s against 48.4 at 4,096 boards
+    // (tools/ab_trunk.py; 3 spills), whatever AQG_BIAS_STEP frees -- and the -26 % of the AQG_ABL_LDSA row is its constant operands'
+    // clock (DVFS), not these reads.
+#ifndef AQG_LIN_AHEAD
+#define AQG_LIN_AHEAD 1
+#endif
+    constexpr int D = AQG_LIN_AHEAD;
+    u32x4 ring[D + 1][2];
     auto frag_off = [&](int step) -> int {                  // step = m*4 + kb
         const int m = step >> 2, kb = step & 3;
         const int row = (m < 5) ? 16 * m + c : 80;
         return plane_off(row, 4 * kb + q);
     };
+    auto request = [&](int step) {
+#ifdef AQG_ABL_LDSA
+        ring[step % (D + 1)][0] = ring[(step + D) % (D + 1)][1]; ring[step % (D + 1)][1] = ring[(step + D) % (D + 1)][0];
+#else
+        const int o = frag_off(step);
+        ring[step % (D + 1)][0] = *reinterpret_cast<const u32x4*>(&sm.P[0][o]);
+        ring[step % (D + 1)][1] = *reinterpret_cast<const u32x4*>(&sm.P[1][o]);
+#endif
+    };
     {
         const int o = frag_off(0);
-        cur[0] = *reinterpret_cast<const u32x4*>(&sm.P[0][o]);
-        cur[1] = *reinterpret_cast<const u32x4*>(&sm.P[1][o]);
+        ring[0][0] = *reinterpret_cast<const u32x4*>(&sm.P[0][o]);
+        ring[0][1] = *reinterpret_cast<const u32x4*>(&sm.P[1][o]);
     }
+#pragma unroll
+    for (int i = 1; i < D; ++i) request(i);
     f32x4 acc[JT], done[JT];
 #pragma unroll
     for (int step = 0; step < 24; ++step) {
         const int m = step >> 2, kb = step & 3;
-        if (step < 23) {
-#ifdef AQG_ABL_LDSA
-            nxt[0] = cur[1]; nxt[1] = cur[0];
-#else
-            const int o = frag_off(step + 1);
-            nxt[0] = *reinterpret_cast<const u32x4*>(&sm.P[0][o]);
-            nxt[1] = *reinterpret_cast<const u32x4*>(&sm.P[1][o]);
-#endif
-        }
+        if (step == AQG_BIAS_STEP) mid();
+        if (step + D < 24) request(step + D);
         __builtin_amdgcn_sched_barrier(0);
+        const u32x4 hi = ring[step % (D + 1)][0], lo = ring[step % (D + 1)][1];
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             f32x4 a = kb == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[j];
 #ifdef AQG_ABL_LIN     // timing-only ablation (tools/ab_trunk.py): the linear map's MFMAs removed, its LDS reads and splits kept alive
-            asm volatile("" : "+v"(a) : "v"(cur[0]), "v"(cur[1]), "v"(Bf[0][j][kb]), "v"(Bf[1][j][kb]));
+            asm volatile("" : "+v"(a) : "v"(hi), "v"(lo), "v"(Bf[0][j][kb]), "v"(Bf[1][j][kb]));
 #else
-            a = mfma_f16(cur[1], Bf[0][j][kb], a);
-            a = mfma_f16(cur[0], Bf[1][j][kb], a);
-            a = mfma_f16(cur[0], Bf[0][j][kb], a);
+            a = mfma_f16(lo, Bf[0][j][kb], a);
+            a = mfma_f16(hi, Bf[1][j][kb], a);
+            a = mfma_f16(hi, Bf[0][j][kb], a);
 #endif
             acc[j] = a;
             if (m > 0 && kb < 3) split_tile_piece(done[j], m - 1, kb, zh[j], zl[j]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (step < 23) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
         if (kb == 3) {
 #pragma unroll
             for (int j = 0; j < JT; ++j) done[j] = acc[j];
@@ -1150,6 +1168,12 @@ __device__ __forceinline__ void trunk_build_inputs(unsigned short (&G16)[81][16]
 constexpr int N = 9, V = 81, NSLOT = NWV == 4 ? 3 : 2;
     const Open op = make_open<N>(hw, vw);
     const Planes pl = degree_planes(op);
+#ifdef AQG_ABL_GP       // timing-only (tools/ab_trunk.py): no layer-1 input rows
+    what &= ~1;
+#endif
+#ifdef AQG_ABL_AFB      // timing-only: no adjacency fragments
+    what &= ~2;
+#endif
     if (what & 1) {
         const int ppos = hd & 0xff, pwl = (hd >> 8) & 0xff, epos = (hd >> 16) & 0xff, ewl = hd >> 24;
         const BB shb = spread_slots<N>(hw), svb = spread_slots<N>(vw);
@@ -1432,8 +1456,7 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
         AQG_STAMP_AT(1)
         // ---- layer 2
         phase_prio(3);
-        request_bias<JT>(out, rs, 1, toff, wave);
-        linear_split<JT>(sm, Bf, lane, zh, zl);
+        linear_split<JT>(sm, Bf, lane, zh, zl, [&]() { request_bias<JT>(out, rs, 1, toff, wave); });
         AQG_STAMP_AT(2)
         // the adjacency fragments, here: the layer-2 weight fragments are dead (32 registers free), the layer-3 ones not yet
         // requested, and the waves that finish the linear map first wait at the next barrier anyway
@@ -1454,7 +1477,6 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
         AQG_STAMP_AT(3)
         // ---- layer 3 + mean pool
         phase_prio(5);
-        request_bias<JT>(out, rs, 2, toff, wave);
         if (AQG_PREFETCH && bn < B) {
             // the NEXT board's G' rows and adjacency fragments, into the other buffers: vector / scalar / LDS work that the two
             // resident workgroups' matrix phases cover, instead of a setup phase in front of every board
@@ -1464,7 +1486,7 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
             build_inputs(par ^ 1, hw, vw, hd, AQG_AF_AT == 0 ? 3 : 1);
         }
         AQG_STAMP_AT(10)
-        linear_split<JT>(sm, Bf, lane, zh, zl);
+        linear_split<JT>(sm, Bf, lane, zh, zl, [&]() { request_bias<JT>(out, rs, 2, toff, wave); });
         AQG_STAMP_AT(4)
         AQG_STAMP_AT(15)
         if constexpr (FUSE) {
