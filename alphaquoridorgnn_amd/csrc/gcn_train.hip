@@ -1293,8 +1293,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
     };
     unsigned int msk[3] = {0u, 0u, 0u};                                 // ReLU masks of the three layers: bit 4 nt + r, R layout
     u32x4 hh[3], hl[3];                                                 // R form of H_l (lane = feature c, nodes 16 nt + 4 q + r) as fragments
-    auto park_tile = [&](int nt, f32x4 v, unsigned int& m) {
-        trk(mx, v);
+    auto park_tile = [&](int nt, f32x4 v, unsigned int& m) {       // (the same values as the T form, which store_plane_tile has range-checked)
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (v[r] > 0.f && live_row(nt, q, r)) m |= 1u << (4 * nt + r);
         v = relu4i(v);
@@ -1362,8 +1361,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const float a0 = wt[8 * kb + 2 * p], a1 = wt[8 * kb + 2 * p + 1];
-                trk(mx, a0, a1);
-                Bh[kb][p] = cvt_pk_f16(a0, a1);
+                Bh[kb][p] = cvt_pk_f16(a0, a1);                 // (range-checked as W_l's rows by split_w: the eight waves' rows are the whole matrix)
                 Bl[kb][p] = lo_pair(Bh[kb][p], a0, a1);
             }
             mfma_fence(Bl[kb]);
@@ -1425,8 +1423,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
     auto aggregate_back = [&](bool planes) {
         if (planes)
             aggregate_tr<true, true>(sm.AF, zh, zl, zero4, zero4, lane, [&](int nt, const f32x4& oT, const f32x4& oR) {
-                store_plane_tile(nt, oT, false);                        // dZ_l: A operand of the next data gradient
-                trk(mx, oR);
+                store_plane_tile(nt, oT, false);                        // dZ_l: A operand of the next data gradient (range-checked there; oR repeats it)
                 split_tile(oR, nt, ah, al);
             });
         else
