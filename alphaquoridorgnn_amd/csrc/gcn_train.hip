@@ -1057,13 +1057,26 @@ __device__ __forceinline__ void trk(Rng& m, const f32x4 v) { trk(m, v[0], v[1]);
 __device__ __forceinline__ f32x4 relu4i(const f32x4 v) { return f32x4{relu1i(v[0]), relu1i(v[1]), relu1i(v[2]), relu1i(v[3])}; }
 __device__ __forceinline__ void mfma_fence(u32x4& a) { asm volatile("s_nop 3" : "+v"(a)); }
 // tile m of a [nodes][16] accumulator image -> dwords 2 (m & 1), + 1 of k block m >> 1 of its hi / lo node-contraction fragments
-__device__ __forceinline__ void split_tile(const f32x4 z, int m, u32x4 (&zh)[3], u32x4 (&zl)[3]) {
+// The range check of two values that are being split: ONE v_max3_f32 with |.| modifiers (fmaxf(|a|, |b|) costs the compiler a
+// canonicalising v_max per operand on top).  As an asm statement it must not be the first reader of a matrix-pipe result (hipcc pads
+// nothing for asm): `dep` is the packed fp16 pair the compiler-visible v_cvt_pk has just made of the same two values, so the check
+// sits behind that instruction, the way lo_pair() does.
+__device__ __forceinline__ void trk_after(Rng& m, unsigned int dep, float a, float b) {
+#ifdef AQG_INT_TRK
+    (void)dep; trk(m, a, b);
+#else
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m.m) : "v"(a), "v"(b), "v"(dep));
+#endif
+}
+__device__ __forceinline__ void split_tile(const f32x4 z, int m, u32x4 (&zh)[3], u32x4 (&zl)[3], Rng* rng = nullptr) {
     const int kb = m >> 1, d = 2 * (m & 1);
     zh[kb][d] = cvt_pk_f16(z[0], z[1]); zh[kb][d + 1] = cvt_pk_f16(z[2], z[3]);
+    if (rng) { trk_after(*rng, zh[kb][d], z[0], z[1]); trk_after(*rng, zh[kb][d + 1], z[2], z[3]); }
     zl[kb][d] = lo_pair(zh[kb][d], z[0], z[1]); zl[kb][d + 1] = lo_pair(zh[kb][d + 1], z[2], z[3]);
 }
-__device__ __forceinline__ void plane_store4(unsigned char (&P)[2][PPLANE], int off, const f32x4 v) {
+__device__ __forceinline__ void plane_store4(unsigned char (&P)[2][PPLANE], int off, const f32x4 v, Rng* rng = nullptr) {
     const unsigned int h01 = cvt_pk_f16(v[0], v[1]), h23 = cvt_pk_f16(v[2], v[3]);
+    if (rng) { trk_after(*rng, h01, v[0], v[1]); trk_after(*rng, h23, v[2], v[3]); }
     *reinterpret_cast<u32x2*>(&P[0][off]) = (u32x2){h01, h23};
     *reinterpret_cast<u32x2*>(&P[1][off]) = (u32x2){lo_pair(h01, v[0], v[1]), lo_pair(h23, v[2], v[3])};
 }
@@ -1073,7 +1086,7 @@ __device__ __forceinline__ bool live_row(int nt, int q, int r) { return nt < 5 |
 // fp16 terms, smallest first); post(m, tile) sees every finished tile before it is split into the node-contraction fragments.
 template <class Post>
 __device__ __forceinline__ void linear_split_post(const unsigned char (&P)[2][PPLANE], const u32x4 (&Bh)[4], const u32x4 (&Bl)[4], int lane,
-                                                  u32x4 (&zh)[3], u32x4 (&zl)[3], Post post) {
+                                                  u32x4 (&zh)[3], u32x4 (&zl)[3], Rng& rng, Post post) {
     const int c = lane & 15, q = lane >> 4;
     // The fragments of step s + AQG_TRAIN_FRAG_AHEAD are requested while step s multiplies (a ring of that many register pairs).
     // One step ahead is enough: 2 / 3 / 5 steps measured 0.0568 / 0.0572 / 0.0613 ms per step against 0.0565 (tools/ab_train.sh) --
@@ -1107,12 +1120,12 @@ __device__ __forceinline__ void linear_split_post(const unsigned char (&P)[2][PP
         a = mfma_f16(hi, Bh[kb], a);
         acc = a;
         // the finished tile m - 1 is masked / checked and split under tile m's first MFMA group
-        if (m > 0 && kb == 0) { post(m - 1, done); split_tile(done, m - 1, zh, zl); }
+        if (m > 0 && kb == 0) { post(m - 1, done); split_tile(done, m - 1, zh, zl, &rng); }
         __builtin_amdgcn_sched_barrier(0);
         if (kb == 3) done = acc;
     }
     post(5, done);
-    split_tile(done, 5, zh, zl);
+    split_tile(done, 5, zh, zl, &rng);
 }
 
 // Both forms of the aggregation over the ten blocks (header of this section), node tile by node tile: the blocks of a tile are
@@ -1198,8 +1211,9 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             const f32x4 a = wf[2 * kb], bb = wf[2 * kb + 1];
-            trk(mx, a); trk(mx, bb);
             Bh[kb] = (u32x4){cvt_pk_f16(a[0], a[1]), cvt_pk_f16(a[2], a[3]), cvt_pk_f16(bb[0], bb[1]), cvt_pk_f16(bb[2], bb[3])};
+            trk_after(mx, Bh[kb][0], a[0], a[1]); trk_after(mx, Bh[kb][1], a[2], a[3]);
+            trk_after(mx, Bh[kb][2], bb[0], bb[1]); trk_after(mx, Bh[kb][3], bb[2], bb[3]);
             Bl[kb] = (u32x4){lo_pair(Bh[kb][0], a[0], a[1]), lo_pair(Bh[kb][1], a[2], a[3]), lo_pair(Bh[kb][2], bb[0], bb[1]), lo_pair(Bh[kb][3], bb[2], bb[3])};
             mfma_fence(Bl[kb]);
         }
@@ -1278,8 +1292,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
             if (q != 0) xa = (u32x4){0u, 0u, 0u, 0u};
             f32x4 z = mfma_f16(xa, w1l, (f32x4){0.f, 0.f, 0.f, 0.f});
             z = mfma_f16(xa, w1h, z);
-            trk(mx, z);
-            split_tile(z, m, zh, zl);
+            split_tile(z, m, zh, zl, &mx);
         }
     }
     __syncthreads();                                                   // A_hat fragments complete
@@ -1287,9 +1300,8 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
     // ---- forward epilogues
     const int poff = (2 * wave + (q >> 1)) /* 16-byte slot of features 16 w + 4 q .. */, pbyte = 8 * (q & 1);
     auto store_plane_tile = [&](int nt, f32x4 v, bool relu) {          // T form: lane = node c of tile nt, features 16 w + 4 q + r
-        trk(mx, v);
-        if (relu) v = relu4i(v);
-        if (nt < 5 || c == 0) plane_store4(sm.P, plane_off(16 * nt + c, poff) + pbyte, v);
+        if (relu) v = relu4i(v);                                        // (what is split is range-checked: a pre-activation below -65504 is a zero)
+        if (nt < 5 || c == 0) plane_store4(sm.P, plane_off(16 * nt + c, poff) + pbyte, v, &mx);
     };
     unsigned int msk[3] = {0u, 0u, 0u};                                 // ReLU masks of the three layers: bit 4 nt + r, R layout
     u32x4 hh[3], hl[3];                                                 // R form of H_l (lane = feature c, nodes 16 nt + 4 q + r) as fragments
@@ -1319,7 +1331,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
     __syncthreads();                                                    // planes of H1 complete
     TS(9, 2)
     // ---- layer 2
-    linear_split_post(sm.P, Bh, Bl, lane, zh, zl, [&](int, f32x4& z) { trk(mx, z); });
+    linear_split_post(sm.P, Bh, Bl, lane, zh, zl, mx, [&](int, f32x4&) {});
 #pragma unroll
     for (int kb = 0; kb < 3; ++kb) mfma_fence(zl[kb]);
     __syncthreads();                                                    // everybody has read the planes of H1
@@ -1333,13 +1345,13 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
     __syncthreads();                                                    // planes of H2 complete
     TS(9, 4)
     // ---- layer 3 (R form only: its ReLU mask and the mean pool; H3 itself is not needed again)
-    linear_split_post(sm.P, Bh, Bl, lane, zh, zl, [&](int, f32x4& z) { trk(mx, z); });
+    linear_split_post(sm.P, Bh, Bl, lane, zh, zl, mx, [&](int, f32x4&) {});
 #pragma unroll
     for (int kb = 0; kb < 3; ++kb) mfma_fence(zl[kb]);
     {
         float s = 0.f;
         aggregate_tr<false, true>(sm.AF, zh, zl, bT2, (f32x4){bR3, bR3, bR3, bR3}, lane, [&](int nt, const f32x4&, const f32x4& oR) {
-            trk(mx, oR);
+            // (H3 is not split: only its signs and its f32 column sums are used)
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (oR[r] > 0.f && live_row(nt, q, r)) { msk[2] |= 1u << (4 * nt + r); s += oR[r]; }
         });
@@ -1428,8 +1440,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
             });
         else
             aggregate_tr<false, true>(sm.AF, zh, zl, zero4, zero4, lane, [&](int nt, const f32x4&, const f32x4& oR) {
-                trk(mx, oR);
-                split_tile(oR, nt, ah, al);
+                split_tile(oR, nt, ah, al, &mx);
             });
     };
     auto weight_grad = [&](float* __restrict__ pdW) {                   // dW_l[all j][this wave's k]: A = parked H_{l-1}, B = FR (all waves)
@@ -1485,7 +1496,7 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
                 DBG_PUT(2, B, b, n, f, ((float)*reinterpret_cast<const _Float16*>(&sm.P[0][o]) + (float)*reinterpret_cast<const _Float16*>(&sm.P[1][o])) * inv_s)
             }
 #endif
-        linear_split_post(sm.P, Bh, Bl, lane, zh, zl, [&](int mt, f32x4& z) {
+        linear_split_post(sm.P, Bh, Bl, lane, zh, zl, mx, [&](int mt, f32x4& z) {
 #ifdef AQG_TRAIN_DEBUG
             if (layer == 1) for (int r = 0; r < 4; ++r) if (live_row(mt, q, r)) DBG_PUT(1, B, b, 16 * mt + 4 * q + r, col, z[r] * inv_s)
 #endif
@@ -1494,7 +1505,6 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
 #ifdef AQG_TRAIN_DEBUG
             if (layer == 1) for (int r = 0; r < 4; ++r) if (live_row(mt, q, r)) DBG_PUT(0, B, b, 16 * mt + 4 * q + r, col, z[r] * inv_s)
 #endif
-            trk(mx, z);
         });
         store_db(sdb, layer);
 #pragma unroll
