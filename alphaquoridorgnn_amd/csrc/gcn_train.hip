@@ -1051,8 +1051,14 @@ __device__ __forceinline__ float relu1i(float x) { return __builtin_bit_cast(flo
 struct Rng { float m = 0.f; };
 __device__ __forceinline__ void trk(Rng& m, float a, float b) { m.m = fmaxf(m.m, fmaxf(fabsf(a), fabsf(b))); }
 __device__ __forceinline__ bool out_of_fp16_range(const Rng& m) { return !(m.m <= 65504.0f); }
+#ifdef AQG_ABL_FLOAT_RELU
 __device__ __forceinline__ float relu1i(float x) { return fmaxf(x, 0.f); }
+#else   // relu on the bit pattern: one v_max_i32, no canonicalising v_max on top (through a scalar parameter: see above)
+__device__ __forceinline__ float relu1i(float x) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0)); }
 #endif
+#endif
+// 1 if x > 0 else 0, on the bit pattern (a positive float is a positive integer): one v_med3_i32
+__device__ __forceinline__ unsigned int positive_bit(float x) { return (unsigned int)min(max(__builtin_bit_cast(int, x), 0), 1); }
 __device__ __forceinline__ void trk(Rng& m, const f32x4 v) { trk(m, v[0], v[1]); trk(m, v[2], v[3]); }
 __device__ __forceinline__ f32x4 relu4i(const f32x4 v) { return f32x4{relu1i(v[0]), relu1i(v[1]), relu1i(v[2]), relu1i(v[3])}; }
 __device__ __forceinline__ void mfma_fence(u32x4& a) { asm volatile("s_nop 3" : "+v"(a)); }
@@ -1307,7 +1313,11 @@ __device__ __forceinline__ bool train_board_split_body(unsigned char* __restrict
     u32x4 hh[3], hl[3];                                                 // R form of H_l (lane = feature c, nodes 16 nt + 4 q + r) as fragments
     auto park_tile = [&](int nt, f32x4 v, unsigned int& m) {       // (the same values as the T form, which store_plane_tile has range-checked)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (v[r] > 0.f && live_row(nt, q, r)) m |= 1u << (4 * nt + r);
+        for (int r = 0; r < 4; ++r) {                                  // (a NaN would count as positive: the range guard has long fired then)
+            const float x = v[r];
+            if (nt < 5) m |= positive_bit(x) << (4 * nt + r);
+            else if (live_row(nt, q, r)) m |= positive_bit(x) << (4 * nt + r);
+        }
         v = relu4i(v);
         split_tile(v, nt, hh, hl);
     };
