@@ -1604,23 +1604,26 @@ __device__ __forceinline__ void adam_update(const FinalJobs& jb, int i, unsigned
     const float denom = sqrtf(vi) / jb.bc2_sqrt + jb.eps;
     jb.p[i][e] = o.p - (jb.lr / jb.bc1) * (mi / denom);
 }
-// A workgroup = 32 lanes x 8 board groups: a thread sums its group's boards in order, the 8 group sums are added in group
-// order -- a fixed summation order with 8x the loads in flight of one thread per element.  The first FINAL_BIG_BLOCKS
-// workgroups take the two [128,128] trunk weights four elements per lane (16-byte loads of the 16 MB of per-board
-// partials); the rest take every other tensor one element per lane (end[] counts those tensors only).
-// A "row" = such a team of 256 threads; a workgroup = FINAL_TEAMS rows (1,246 four-wave workgroups took longer to LAUNCH than to
-// run: the same rows as 312 sixteen-wave workgroups).
+// A team = 32 lanes x FINAL_GROUPS board groups: a thread sums its group's boards in order, the group sums are added pairwise in
+// group order -- a fixed summation order with FINAL_GROUPS x the loads in flight of one thread per element.  The first
+// FINAL_BIG_BLOCKS teams ("rows") take the two [128,128] trunk weights four elements per lane (16-byte loads of the 16 MB of
+// per-board partials); the rest take every other tensor one element per lane (end[] counts those tensors only).  A workgroup =
+// FINAL_TEAMS teams = 1,024 threads.
 constexpr int FINAL_BIG_BLOCKS = 2 * TH * TH / 128;
-constexpr int FINAL_TEAMS = 4;
-__global__ __launch_bounds__(256 * FINAL_TEAMS) void train_final_kernel(FinalJobs jb) {
-    __shared__ f32x4 red4s[FINAL_TEAMS][8][33];
+#ifndef AQG_FINAL_GROUPS
+#define AQG_FINAL_GROUPS 4          // board groups per element: a thread sums B / groups boards (4 / 8 / 16 groups: 0.0467 / 0.0473 / 0.0527 ms per step)
+#endif
+constexpr int FINAL_GROUPS = AQG_FINAL_GROUPS, FINAL_TEAM_THREADS = 32 * FINAL_GROUPS;
+constexpr int FINAL_TEAMS = 1024 / FINAL_TEAM_THREADS;
+__global__ __launch_bounds__(FINAL_TEAM_THREADS * FINAL_TEAMS) void train_final_kernel(FinalJobs jb) {
+    __shared__ f32x4 red4s[FINAL_TEAMS][FINAL_GROUPS][33];
     TS_DECL
-    const int team = threadIdx.x >> 8, tt = threadIdx.x & 255;
+    const int team = threadIdx.x / FINAL_TEAM_THREADS, tt = threadIdx.x % FINAL_TEAM_THREADS;
     const unsigned int row = blockIdx.x * FINAL_TEAMS + team;
     f32x4 (*red4)[33] = red4s[team];
     const int le = tt & 31, grp = tt >> 5;
     const int B = jb.B, A = jb.A;
-    const int per = (B + 7) / 8, b0 = grp * per, b1 = min(B, b0 + per);
+    const int per = (B + FINAL_GROUPS - 1) / FINAL_GROUPS, b0 = grp * per, b1 = min(B, b0 + per);
     if (row < FINAL_BIG_BLOCKS) {
         const unsigned int q4 = row * 32 + le;                    // float4 index over gcn1.w then gcn2.w
         const int i = q4 < TH * TH / 4 ? 2 : 4;
@@ -1640,7 +1643,9 @@ __global__ __launch_bounds__(256 * FINAL_TEAMS) void train_final_kernel(FinalJob
             __syncthreads();
             TS(6, 1)
             if (grp != 0) return;
-            gr4 = ((red4[0][le] + red4[1][le]) + (red4[2][le] + red4[3][le])) + ((red4[4][le] + red4[5][le]) + (red4[6][le] + red4[7][le]));
+            gr4 = (red4[0][le] + red4[1][le]) + (red4[2][le] + red4[3][le]);
+            if (FINAL_GROUPS >= 8) gr4 += (red4[4][le] + red4[5][le]) + (red4[6][le] + red4[7][le]);
+            if (FINAL_GROUPS == 16) gr4 += ((red4[8][le] + red4[9][le]) + (red4[10][le] + red4[11][le])) + ((red4[12][le] + red4[13][le]) + (red4[14][le] + red4[15][le]));
             st4(jb.g[i] + e, gr4);
         } else {
             if (grp != 0) return;
@@ -1706,7 +1711,9 @@ __global__ __launch_bounds__(256 * FINAL_TEAMS) void train_final_kernel(FinalJob
     if (grp != 0 || !live) return;
     float gr;
     if (jb.compute) {
-        gr = ((red[0][le] + red[1][le]) + (red[2][le] + red[3][le])) + ((red[4][le] + red[5][le]) + (red[6][le] + red[7][le]));
+        gr = (red[0][le] + red[1][le]) + (red[2][le] + red[3][le]);
+        if (FINAL_GROUPS >= 8) gr += (red[4][le] + red[5][le]) + (red[6][le] + red[7][le]);
+        if (FINAL_GROUPS == 16) gr += ((red[8][le] + red[9][le]) + (red[10][le] + red[11][le])) + ((red[12][le] + red[13][le]) + (red[14][le] + red[15][le]));
         if (i == 14) { jb.loss_sums[e] += gr / (float)B; return; }
         jb.g[i][e] = gr;
     } else {
@@ -1796,7 +1803,7 @@ static int launch_final(const aqg_train& t, int B, bool compute, bool update, in
     const double bc1 = 1.0 - pow((double)t.beta1, (double)step), bc2 = 1.0 - pow((double)t.beta2, (double)step);
     jb.lr = t.lr; jb.beta1 = t.beta1; jb.beta2 = t.beta2; jb.eps = t.eps; jb.bc1 = (float)bc1; jb.bc2_sqrt = (float)sqrt(bc2);
     const unsigned int rows = FINAL_BIG_BLOCKS + (run + 2 + 31) / 32;
-    hipLaunchKernelGGL(train_final_kernel, dim3((rows + FINAL_TEAMS - 1) / FINAL_TEAMS), dim3(256 * FINAL_TEAMS), 0, st, jb);
+    hipLaunchKernelGGL(train_final_kernel, dim3((rows + FINAL_TEAMS - 1) / FINAL_TEAMS), dim3(FINAL_TEAM_THREADS * FINAL_TEAMS), 0, st, jb);
     return check_launch("train_final_kernel");
 }
 
