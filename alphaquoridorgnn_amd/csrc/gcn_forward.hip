@@ -22,6 +22,8 @@
 #include "split_mfma.hpp"
 #include "../../include/aqgnn.h"
 #include <vector>
+#include <cmath>
+#include <algorithm>
 
 namespace aqg {
 
@@ -65,7 +67,10 @@ struct PackedLayout {
     // aggregation accumulator init of the default trunk: TB[layer 3][deg-1 5][HID] = CQ * b_layer[f] * sqrt(deg)
     // (the bias of a node with `deg` neighbours incl. itself, pre-divided by its D^-1/2 factor; see the trunk comment)
     static constexpr size_t TB = WHP2 + 2 * 14 * 2 * 64 * 4;
-    static constexpr size_t TOTAL = TB + 3 * 5 * HID;
+    // range-guard thresholds of the tracking trunk build (GUARD_MODE 2): [0] = largest |U| of layer 2's linear map for which layer 2's
+    // aggregate provably stays below 65504, (65504 - max |TB_2|) / 2.07;  [1] = 65504 (layer 3's U is only split itself);  [2..3] spare
+    static constexpr size_t GUARD = TB + 3 * 5 * HID;
+    static constexpr size_t TOTAL = GUARD + 4;
 };
 
 // Scale of the activation image of the default trunk: the planes hold Q = CQ * relu(...) / D^-1/2.  CQ = 15/16 makes
@@ -186,6 +191,17 @@ int pack_weights_host(int N, const float* const* t, float* out) {
         for (int deg = 1; deg <= 5; ++deg)
             for (int f = 0; f < HID; ++f)
                 out[PackedLayout::TB + ((size_t)L * 5 + (deg - 1)) * HID + f] = (float)(CQ * (double)t[2 * L + 1][f] * sqrt((double)deg));
+    {
+        // |V[n][f]| <= sum_{k in N[n]} |U[k][f]| CQ / deg_k + |TB| <= max|U| * CQ * (1/d_n + (d_n - 1)/2) + max|TB| <= 2.0625 max|U| + max|TB|
+        // (a neighbour has closed degree >= 2): 2.07 with rounding slack
+        double tbmax = 0.0;
+        for (int deg = 1; deg <= 5; ++deg)
+            for (int f = 0; f < HID; ++f) tbmax = std::max(tbmax, std::fabs((double)out[PackedLayout::TB + ((size_t)1 * 5 + (deg - 1)) * HID + f]));
+        const double t2 = (65504.0 - tbmax) / 2.07;
+        out[PackedLayout::GUARD + 0] = (float)(t2 > 0.0 && t2 == t2 ? t2 : 0.0);      // (NaN / negative: every board is reported)
+        out[PackedLayout::GUARD + 1] = 65504.0f;
+        out[PackedLayout::GUARD + 2] = out[PackedLayout::GUARD + 3] = 0.f;
+    }
     for (int u = 0; u < HID / 2; ++u)
         for (int k = 0; k < HID; ++k) {
             out[PackedLayout::HW1T + k * HID + u] = t[6][u * HID + k];
@@ -748,9 +764,23 @@ __device__ __forceinline__ void load_bfrag_mm(u32x4 (&Bf)[2][JT][4], __amdgpu_bu
 // fp16 hi / lo aggregation fragments of one finished 16-node tile m of U (accumulator layout: lane = feature column, 4
 // consecutive nodes): dwords 2 (m & 1), 2 (m & 1) + 1 of k block m >> 1.  `piece` 0 = the two hi dwords, 1 / 2 = one lo dword each,
 // so that the three pieces can be spread over the MFMA groups of the NEXT tile.
-__device__ __forceinline__ void split_tile_piece(const f32x4 z, int m, int piece, u32x4 (&zh)[3], u32x4 (&zl)[3]) {
+// largest |x| of two values that are being split: ONE v_max3_f32 with |.| modifiers, as an asm statement ordered behind the
+// compiler-visible v_cvt_pk of the same two values by `dep` (hipcc pads nothing for asm: it must not be the first reader of a
+// matrix-pipe result -- the way lo_pair() is ordered)
+__device__ __forceinline__ void absmax_after(float& m, unsigned int dep, float a, float b) {
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(a), "v"(b), "v"(dep));
+}
+// the signed form for values that are about to be ReLU-ed (a negative excursion becomes a zero: nothing to report), ordered behind the
+// two compiler-visible instructions that have read a and b (their results d0, d1)
+__device__ __forceinline__ void max_after2(float& m, float d0, float d1, float a, float b) {
+    asm("v_max3_f32 %0, %1, %2, %0" : "+v"(m) : "v"(a), "v"(b), "v"(d0), "v"(d1));
+}
+__device__ __forceinline__ void split_tile_piece(const f32x4 z, int m, int piece, u32x4 (&zh)[3], u32x4 (&zl)[3], float* zmax = nullptr) {
     const int kb = m >> 1, d = 2 * (m & 1);
-    if (piece == 0) { zh[kb][d] = cvt_pk_f16(z[0], z[1]); zh[kb][d + 1] = cvt_pk_f16(z[2], z[3]); }
+    if (piece == 0) {
+        zh[kb][d] = cvt_pk_f16(z[0], z[1]); zh[kb][d + 1] = cvt_pk_f16(z[2], z[3]);
+        if (zmax) { absmax_after(*zmax, zh[kb][d], z[0], z[1]); absmax_after(*zmax, zh[kb][d + 1], z[2], z[3]); }
+    }
     else if (piece == 1) zl[kb][d] = lo_pair(zh[kb][d], z[0], z[1]);
     else zl[kb][d + 1] = lo_pair(zh[kb][d + 1], z[2], z[3]);
 }
@@ -765,7 +795,8 @@ __device__ __forceinline__ void split_tile_piece(const f32x4 z, int m, int piece
 #endif
 struct NoMid { __device__ __forceinline__ void operator()() const {} };
 template <int JT, class SM, class Mid = NoMid>
-__device__ __forceinline__ void linear_split(const SM& sm, const u32x4 (&Bf)[2][JT][4], int lane, u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], Mid mid = Mid()) {
+__device__ __forceinline__ void linear_split(const SM& sm, const u32x4 (&Bf)[2][JT][4], int lane, u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], Mid mid = Mid(),
+                                             float* zmax = nullptr) {
     const int c = lane & 15, q = lane >> 4;
     // the fragments of step s + AQG_LIN_AHEAD are requested while step s multiplies (a ring of that many register pairs).  One step
     // ahead is enough with four waves per SIMD: 2 / 3 steps measured 48.0 / 45.4 M boards/s against 48.4 at 4,096 boards
@@ -816,7 +847,7 @@ __device__ __forceinline__ void linear_split(const SM& sm, const u32x4 (&Bf)[2][
             a = mfma_f16(hi, Bf[0][j][kb], a);
 #endif
             acc[j] = a;
-            if (m > 0 && kb < 3) split_tile_piece(done[j], m - 1, kb, zh[j], zl[j]);
+            if (m > 0 && kb < 3) split_tile_piece(done[j], m - 1, kb, zh[j], zl[j], zmax);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (kb == 3) {
@@ -827,7 +858,7 @@ __device__ __forceinline__ void linear_split(const SM& sm, const u32x4 (&Bf)[2][
 #pragma unroll
     for (int j = 0; j < JT; ++j)
 #pragma unroll
-        for (int piece = 0; piece < 3; ++piece) split_tile_piece(done[j], 5, piece, zh[j], zl[j]);
+        for (int piece = 0; piece < 3; ++piece) split_tile_piece(done[j], 5, piece, zh[j], zl[j], zmax);
 }
 
 // The aggregation accumulators start from the bias: out[nt][j] = TB[layer][deg(node) - 1][this lane's 4 features] = CQ b sqrt(deg),
@@ -849,7 +880,9 @@ __device__ __forceinline__ void request_bias(f32x4 (&out)[6][JT], __amdgpu_buffe
 // The blocks of a node tile are consecutive (a dependent 16x16x32 chain issues at the full rate), so tile nt is complete while
 // tile nt + 1 is still on the matrix pipe: its relu / split / stores are vector and LDS work issued under those MFMAs.
 // (No plane byte is read here: the caller has passed the barrier behind the linear map, the stores are free to go.)
-template <int JT, bool LAST, bool TRACK = true, class SM>
+// TRACK: 0 = no range check here; 1 = every value's bit pattern (track_range); 2 = none here either: the caller has bounded the
+// aggregate by the linear map's output (GUARD_MODE 2 of the kernel)
+template <int JT, bool LAST, int TRACK = 1, class SM>
 __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)[AF_BLOCKS][64][4], u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], f32x4 (&out)[6][JT], int wave, int lane,
                                                 const int (&toff)[3], __amdgpu_buffer_rsrc_t pooled_rs, int pooled_soff, int32_t* __restrict__ saturated,
                                                 float* pooled_lds = nullptr) {
@@ -877,7 +910,7 @@ __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)
         for (int j = 0; j < JT; ++j) {
             f32x4 v = out[nt][j];
             if (LAST) {
-                if (TRACK && live) track_range(v, imax, umax); // (only inf / NaN matter here: the pooled row is f32, the heads check its range)
+                if (TRACK == 1 && live) track_range(v, imax, umax); // (only inf / NaN matter here: the pooled row is f32, the heads check its range)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
 #ifndef AQG_ABL_POOL      // timing-only ablation (tools/ab_trunk.py): the mean pool's arithmetic removed
@@ -888,7 +921,7 @@ __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)
                 // instead of becoming inf - inf = NaN that the next relu would silently turn into 0 -- and is REPORTED (imax):
                 // the host then serves the weight set with the exact-f32 kernels (and checks every set on calibration boards
                 // before it trusts this kernel at all, pv_network_gnn.packed_weights).
-                if (TRACK && live) track_range(v, imax, umax);
+                if (TRACK == 1 && live) track_range(v, imax, umax);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = relu_sat16(v[e]);
                 if (live) store_split4(sm, plane_off(node, (col0 + 16 * j) >> 3) + ((2 * (col0 + 16 * j)) & 15), v);
@@ -913,7 +946,7 @@ __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)
         if (nt > 0 && (blk + 1 == AF_BLOCKS || af_nt(blk + 1) != nt)) epilogue(nt - 1);
     }
     epilogue(5);
-    if (TRACK) report_saturation(LAST ? (imax >= 0x7F800000 || umax >= 0xFF800000u) : out_of_range(imax, umax), saturated);
+    if (TRACK == 1) report_saturation(LAST ? (imax >= 0x7F800000 || umax >= 0xFF800000u) : out_of_range(imax, umax), saturated);
     if (LAST) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -962,12 +995,13 @@ __device__ __forceinline__ float lane_sel(uint64_t m, float a) {
 // rows of G' (lane = node; k-slots of q = 0 / 2 read the hi half, q = 1 the lo half, q = 3 meets zero weight slots), accumulated on
 // the bias rows.  The result already has the store layout (lane = node, 4 consecutive features): relu, fp16 split, plane stores.
 // 6 MFMAs per wave and feature tile where the linear-first form needed 6 + 20 (X0 W1, then the 128-wide banded aggregation).
-template <int JT, bool TRACK = true, class SM>
+template <int JT, int TRACK = 1, class SM>
 __device__ __forceinline__ void layer1_store(SM& sm, const unsigned short (&G)[81][16], const u32x4 (&w1f)[JT], f32x4 (&out)[6][JT],
                                              int wave, int lane, int32_t* __restrict__ saturated) {
     const int c = lane & 15, q = lane >> 4;
     int imax = 0;
     unsigned int umax = 0u;
+    float fmx = 0.f;
     const int col0 = 16 * JT * wave + 4 * q;
     u32x4 gf[6];
 #pragma unroll
@@ -983,13 +1017,19 @@ __device__ __forceinline__ void layer1_store(SM& sm, const unsigned short (&G)[8
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             f32x4 v = out[nt][j];
-            if (TRACK && live) track_range(v, imax, umax);
+            if (TRACK == 1 && live) track_range(v, imax, umax);
+            // mode 2: the pre-clamp values are finite here (finite weights times bounded layer-1 rows: no inf, no NaN) and only a
+            // POSITIVE excursion is clamped, so the largest value is all there is to watch -- a plain float maximum, two values per
+            // instruction (the first reader of these matrix-pipe results is the compiler-visible v_med3 below: the maxima sit behind it)
+            f32x4 w = v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = relu_sat16(v[e]);
+            if (TRACK == 2 && live) { max_after2(fmx, v[0], v[1], w[0], w[1]); max_after2(fmx, v[2], v[3], w[2], w[3]); }
             if (live) store_split4(sm, plane_off(node, (col0 + 16 * j) >> 3) + ((2 * (col0 + 16 * j)) & 15), v);
         }
     }
-    if (TRACK) report_saturation(out_of_range(imax, umax), saturated);
+    if (TRACK == 1) report_saturation(out_of_range(imax, umax), saturated);
+    if (TRACK == 2) report_saturation(!(fmx <= 65504.0f), saturated);
 }
 
 __device__ __forceinline__ uint32_t bit_of64(uint64_t m, int s) {             // bit s of a wave-uniform 64-bit mask
@@ -1309,10 +1349,14 @@ __device__ __forceinline__ void trunk_bias_offsets(uint64_t hw, uint64_t vw, int
 }
 
 // (hipcc's second launch-bound argument is waves per SIMD: workgroups per CU x waves per workgroup / 4 SIMDs)
-// TRACK = false: the caller has PROVEN that no value of this weight set can leave fp16 range on any record with at most
-// AQG_GNN_PROVEN_MAX_WALLS walls in hand (AQG_GNN_RANGE_PROVEN, include/aqgnn.h): the per-value range tracking of the epilogues (one
-// vector instruction per value: 4 % of the kernel) is dropped and each record's two wall counts are checked instead, on the scalar unit.
-template <int JT, int WGS_PER_CU, bool FUSE = false, bool TRACK = true>
+// TRACK (the range guard's mode): 0 = the caller has PROVEN that no value of this weight set can leave fp16 range on any record with at
+// most AQG_GNN_PROVEN_MAX_WALLS walls in hand (AQG_GNN_RANGE_PROVEN, include/aqgnn.h): nothing is tracked, each record's two wall counts
+// are checked instead, on the scalar unit.  2 (every other weight set) = the values are bounded where that is cheapest: layer 1's
+// pre-clamp outputs by a float maximum; the linear maps' outputs U (which are split themselves) by a float maximum of |U| against the
+// thresholds of PackedLayout::GUARD -- layer 2's aggregate is then below 65504 by  |V| <= 2.0625 max|U| + max|TB|,  layer 3's is not
+// split at all (the heads check the pooled row): one vector instruction per TWO values at three places instead of one per value at
+// five (mode 1, the bit-pattern tracking of every epilogue value, still used by the pair form).
+template <int JT, int WGS_PER_CU, bool FUSE = false, int TRACK = 2>
 #ifdef AQG_TRUNK96
 // Experiment build: the 8-wave form capped at 96 vector registers (the compiler only honours a waves-per-SIMD request beyond what
 // the kernel's LDS allows when it cannot see the LDS size, hence dynamic LDS here): four trunk waves then leave 128 registers of a
@@ -1441,7 +1485,7 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
         AQG_STAMP_AT(0)
         phase_prio(1);
         // ---- layer 1: one MFMA per node tile on top of the bias rows, relu, planes
-        if (!TRACK && (((hd >> 8) & 0xffu) > AQG_GNN_PROVEN_MAX_WALLS || (hd >> 24) > AQG_GNN_PROVEN_MAX_WALLS)) report_saturation(true, saturated);
+        if (TRACK == 0 && (((hd >> 8) & 0xffu) > AQG_GNN_PROVEN_MAX_WALLS || (hd >> 24) > AQG_GNN_PROVEN_MAX_WALLS)) report_saturation(true, saturated);
         layer1_store<JT, TRACK>(sm, sm.G16[par], w1f, out, wave, lane, saturated);
         AQG_STAMP_AT(8)
         __builtin_amdgcn_sched_barrier(0);
@@ -1456,7 +1500,11 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
         AQG_STAMP_AT(1)
         // ---- layer 2
         phase_prio(3);
-        linear_split<JT>(sm, Bf, lane, zh, zl, [&]() { request_bias<JT>(out, rs, 1, toff, wave); });
+        {
+            float zmax = 0.f;
+            linear_split<JT>(sm, Bf, lane, zh, zl, [&]() { request_bias<JT>(out, rs, 1, toff, wave); }, TRACK == 2 ? &zmax : nullptr);
+            if (TRACK == 2) report_saturation(!(zmax <= pk[PackedLayout::GUARD + 0]), saturated);
+        }
         AQG_STAMP_AT(2)
         // the adjacency fragments, here: the layer-2 weight fragments are dead (32 registers free), the layer-3 ones not yet
         // requested, and the waves that finish the linear map first wait at the next barrier anyway
@@ -1486,7 +1534,11 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
             build_inputs(par ^ 1, hw, vw, hd, AQG_AF_AT == 0 ? 3 : 1);
         }
         AQG_STAMP_AT(10)
-        linear_split<JT>(sm, Bf, lane, zh, zl, [&]() { request_bias<JT>(out, rs, 2, toff, wave); });
+        {
+            float zmax = 0.f;
+            linear_split<JT>(sm, Bf, lane, zh, zl, [&]() { request_bias<JT>(out, rs, 2, toff, wave); }, TRACK == 2 ? &zmax : nullptr);
+            if (TRACK == 2) report_saturation(!(zmax <= pk[PackedLayout::GUARD + 1]), saturated);
+        }
         AQG_STAMP_AT(4)
         AQG_STAMP_AT(15)
         if constexpr (FUSE) {
@@ -1622,8 +1674,8 @@ __global__ __launch_bounds__(512, 2) void gcn_trunk_pairs_kernel(const void* __r
         const int pn = next_pair(p + gridDim.x);
         __syncthreads();                      // both boards' G' rows are complete; the previous pair is done
         // ---- layer 1
-        if (live0) layer1_store<JT>(sm.bd[0], sm.bd[0].G16, w1f, out[0], wave, lane, saturated);
-        if (live1) layer1_store<JT>(sm.bd[1], sm.bd[1].G16, w1f, out[1], wave, lane, saturated);
+        if (live0) layer1_store<JT, 1>(sm.bd[0], sm.bd[0].G16, w1f, out[0], wave, lane, saturated);
+        if (live1) layer1_store<JT, 1>(sm.bd[1], sm.bd[1].G16, w1f, out[1], wave, lane, saturated);
         __builtin_amdgcn_sched_barrier(0);
         load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights, once for the pair
         __builtin_amdgcn_sched_barrier(0);
@@ -1641,16 +1693,16 @@ __global__ __launch_bounds__(512, 2) void gcn_trunk_pairs_kernel(const void* __r
         if (pn < npairs) { fetch_record(min(2 * pn, B - 1), nrec0[0], nrec1[0]); fetch_record(min(2 * pn + 1, B - 1), nrec0[1], nrec1[1]); }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                                    // every wave is done reading the planes
-        if (live0) aggregate_store<JT, false>(sm.bd[0], sm.bd[0].AF, zh[0], zl[0], out[0], wave, lane, toff[0], prs, 0, saturated);
-        if (live1) aggregate_store<JT, false>(sm.bd[1], sm.bd[1].AF, zh[1], zl[1], out[1], wave, lane, toff[1], prs, 0, saturated);
+        if (live0) aggregate_store<JT, false, 1>(sm.bd[0], sm.bd[0].AF, zh[0], zl[0], out[0], wave, lane, toff[0], prs, 0, saturated);
+        if (live1) aggregate_store<JT, false, 1>(sm.bd[1], sm.bd[1].AF, zh[1], zl[1], out[1], wave, lane, toff[1], prs, 0, saturated);
         __syncthreads();
         // ---- layer 3 + mean pool
         if (live0) request_bias<JT>(out[0], rs, 2, toff[0], wave);
         if (live1) request_bias<JT>(out[1], rs, 2, toff[1], wave);
         if (live0) linear_split<JT>(sm.bd[0], Bf, lane, zh[0], zl[0]);
         if (live1) linear_split<JT>(sm.bd[1], Bf, lane, zh[1], zl[1]);
-        if (live0) aggregate_store<JT, true>(sm.bd[0], sm.bd[0].AF, zh[0], zl[0], out[0], wave, lane, toff[0], prs, (2 * p) * (HID * 4), saturated);
-        if (live1) aggregate_store<JT, true>(sm.bd[1], sm.bd[1].AF, zh[1], zl[1], out[1], wave, lane, toff[1], prs, (2 * p + 1) * (HID * 4), saturated);
+        if (live0) aggregate_store<JT, true, 1>(sm.bd[0], sm.bd[0].AF, zh[0], zl[0], out[0], wave, lane, toff[0], prs, (2 * p) * (HID * 4), saturated);
+        if (live1) aggregate_store<JT, true, 1>(sm.bd[1], sm.bd[1].AF, zh[1], zl[1], out[1], wave, lane, toff[1], prs, (2 * p + 1) * (HID * 4), saturated);
         rec0[0] = nrec0[0]; rec0[1] = nrec0[1]; rec1[0] = nrec1[0]; rec1[1] = nrec1[1];
         // (no barrier at the end of a pair: see the one-board form)
         p = pn;
@@ -2106,7 +2158,7 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
                                N * N + 2 * (N - 1) * (N - 1), logits, policy, value_pre, value, saturated);
             fused = true;
         } else if ((flags & AQG_GNN_RANGE_PROVEN) && saturated) {
-            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2, false, false>), dim3(grid), dim3(512), AQG_TRUNK_DYN(8), st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),
+            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2, false, 0>), dim3(grid), dim3(512), AQG_TRUNK_DYN(8), st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),
                                0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, saturated);
         } else {
             hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), AQG_TRUNK_DYN(8), st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),

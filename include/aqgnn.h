@@ -94,6 +94,9 @@ int aqg_state_status(int board_size, const uint8_t* states72, int B, int plies_f
  *   WH2, WH3     fp16 hi/lo planes of W2^T / W3^T in 16x16x32 MFMA B-fragment order (default trunk)
  *   WH1          fp16 hi/lo of (15/16) gcn_layers.0.lin.weight as A fragments, rows = output features, the split folded into one
  *                32-deep k block (default trunk: layer 1 runs aggregate-first, (A_hat X) W1)
+ *   WHH1, WHP2   the heads' matrices as fp16 hi/lo fragments;  TB  bias rows (15/16) b sqrt(deg) per layer and degree;
+ *   GUARD [4]    thresholds of the trunk's fp16-range guard on the linear maps' outputs: [0] = (65504 - max |TB of layer 2|) / 2.07
+ *                (below it layer 2's aggregate provably stays under 65504), [1] = 65504, [2..3] spare (ABI 8: the last four floats)
  * aqg_gcn_packed_floats() returns the total; aqg_gcn_pack_weights_host() fills a HOST buffer from the 14
  * state_dict tensors given as HOST float32 pointers in the key order of KEYS in INTEGRATION.md. */
 size_t aqg_gcn_packed_floats(int board_size);
@@ -132,7 +135,8 @@ int aqg_gcn_forward_boards(int board_size, const void* states, int state_fmt, in
                            int flags, void* stream);
 /* The same call with the runtime fp16-range guard: `saturated` (device int32, may be NULL) is OR-ed with 1 by any fp16-split
  * kernel of the call that met a value it cannot hold as an fp16 pair -- a linear-map output or a post-ReLU activation beyond
- * 65504 (the activation is clamped there, never inf / NaN), a pooled feature or head hidden unit beyond it.  The results of such
+ * 65504 (the activation is clamped there, never inf / NaN), a pooled feature or head hidden unit beyond it -- or could not rule one
+ * out (the trunk bounds layer 2's aggregate by its linear map's output: a linear-map output beyond GUARD[0], about 31,600, is reported).  The results of such
  * a call are finite but not the network's: the caller repeats it with AQG_GNN_EXACT_F32 and keeps that flag for the weight set
  * (GraphPolicyValueNetwork.forward_states / predict do; the engine reports the same event in counters[5]).  The word is never
  * cleared by the library.  Exact-f32 calls never set it.  Reference behaviour: fp32 throughout, no cliff (pv_network_gnn.py:53-64). */

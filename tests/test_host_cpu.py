@@ -110,7 +110,10 @@ def test_weight_packing_layout():
     WHH1 = WH1 + 4 * 2 * 64 * 4
     WHP2 = WHH1 + 2 * 8 * 4 * 64 * 4
     TB = WHP2 + 2 * 14 * 2 * 64 * 4
-    assert n == TB + 3 * 5 * 128
+    GUARD = TB + 3 * 5 * 128                                               # the range guard's thresholds: the last four floats
+    assert n == GUARD + 4
+    tb2 = 15.0 / 16.0 * np.sqrt(5.0) * np.abs(p["gcn_layers.1.bias"].astype(np.float64)).max()
+    assert abs(out[GUARD] - (65504.0 - tb2) / 2.07) <= 1e-2 and out[GUARD + 1] == 65504.0 and not out[GUARD + 2:].any()
     CQ = 15.0 / 16.0                                                       # scale of the default trunk's activation image
     wf2 = out[WF2:WF2 + 128 * 128].reshape(4, 2, 8, 64, 4)                 # [wave][ntile][s4][lane][i]
     for (w, j, s4, lane, i) in [(0, 0, 0, 0, 0), (3, 1, 7, 63, 3), (2, 0, 5, 17, 2), (1, 1, 2, 40, 1)]:
