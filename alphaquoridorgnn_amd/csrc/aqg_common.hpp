@@ -22,7 +22,7 @@ inline int check_launch(const char* kernel) {
 constexpr int WAVE = 64;
 
 // Diagnostic build only (-DAQG_TRACE, tools/trace_overlap.py; never shipped): every workgroup of the three per-simulation
-// kernels logs {kernel id | tag, blockIdx, start, end} (s_memrealtime, 100 MHz) into a caller-supplied buffer whose first
+// kernels logs {kernel id | where it ran, tag, blockIdx, start, end} (s_memrealtime, 100 MHz) into a caller-supplied buffer whose first
 // word is the entry counter -- the only way to see which kernels of different game sets REALLY run side by side (rocprofv3's
 // kernel trace serialises the dispatches it intercepts).
 #ifdef AQG_TRACE
@@ -37,9 +37,10 @@ constexpr int WAVE = 64;
 #define g_trace_cap AQG_CAT(g_trace_cap_, AQG_TRACE_TU)
 static __device__ unsigned long long* g_trace_buf = nullptr;
 static __device__ unsigned int g_trace_cap = 0;
-#define AQG_TRACE_BEGIN unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+#define AQG_TRACE_BEGIN unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime(); unsigned int tr_hw, tr_xcc; \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(tr_hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(tr_xcc));
 #define AQG_TRACE_END(kid, tag) { __syncthreads(); if (threadIdx.x == 0 && g_trace_buf) { const unsigned int i = atomicAdd(reinterpret_cast<unsigned int*>(g_trace_buf), 1u); \
-    if (i < g_trace_cap) { unsigned long long* r = g_trace_buf + 1 + 4ull * i; r[0] = (unsigned long long)(kid); r[1] = (unsigned long long)(tag); r[2] = tr_t0; r[3] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)blockIdx.x << 48); } } }
+    if (i < g_trace_cap) { unsigned long long* r = g_trace_buf + 1 + 4ull * i; r[0] = (unsigned long long)(kid) | ((unsigned long long)(tr_hw & 0xFFFFu) << 8) | ((unsigned long long)(tr_xcc & 0xFu) << 24);   /* bits 8..23: HW_ID (wave, SIMD, pipe, CU, SH, SE), 24..27: XCC */ r[1] = (unsigned long long)(tag); r[2] = tr_t0; r[3] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)blockIdx.x << 48); } } }
 #define AQG_TRACE_SETTER(name) int name(void* buf, unsigned int cap) { unsigned long long* b = (unsigned long long*)buf; \
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &b, sizeof(b)) != hipSuccess) return -1; \
     return hipMemcpyToSymbol(HIP_SYMBOL(g_trace_cap), &cap, sizeof(cap)) == hipSuccess ? 0 : -1; }

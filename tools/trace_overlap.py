@@ -37,7 +37,7 @@ eng.move(); eng.sync(); torch.cuda.synchronize()
 _lib.check(lib.aqg_debug_trace(None, 0), "trace off")
 n = int(buf[0].item()) & 0xFFFFFFFF
 raw = buf[1:1 + 4 * min(n, CAP)].cpu().numpy().reshape(-1, 4)
-kid, tag, t0 = raw[:, 0], raw[:, 1], raw[:, 2]
+kid, tag, t0 = raw[:, 0] & 0xFF, raw[:, 1], raw[:, 2]
 t1 = raw[:, 3] & ((1 << 48) - 1)
 print(f"{n} workgroup records; clock 100 MHz (10 ns ticks)")
 names = {1: "step", 2: "trunk", 3: "heads"}
