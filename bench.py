@@ -519,9 +519,10 @@ def main():
                                          "PMC-measured bytes of this round: profiles/r03_pmc_summary.csv (collected by a separate rocprofv3 pass, "
                                          "quoted in DESIGN.md section 5); the algorithmic layer-granular figure is 169,760 B/board (hbm_frac_survey_formula)",
                          "frac_vs_dense_f16_peak": achieved / PEAK_F16_MFMA,
-                         "mfma_busy_pmc": {"boards_per_launch_65536": 0.49, "boards_per_launch_480": 0.41,
+                         "mfma_busy_pmc": {"boards_per_launch_65536": 0.52, "boards_per_launch_480": 0.31,
                                            "source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) from the separate rocprofv3 --pmc passes of "
-                                                     "this round, profiles/r03_pmc_summary.csv (480: against the un-instrumented launch time); a recorded "
+                                                     "this round, profiles/r03_pmc_summary.csv (480: busy cycles against the un-instrumented 12.99 us launch x 2.4 GHz x 1024 SIMDs; "
+                                                     "0.20 against the counter pass's own, instrumented, GRBM_GUI_ACTIVE); a recorded "
                                                      "measurement, not taken in this run"},
                          "launches": trunk_launches, "avg_launch_us": trunk_ms / max(trunk_launches, 1) * 1e3,
                          "boards_per_launch_avg": trunk_boards / max(trunk_launches, 1),
