@@ -30,21 +30,28 @@ def child(variant):
     m = GNNNetwork().to("cuda").eval()
     pk = m.packed_weights(dev)
     st = torch.from_numpy(recs).to(dev)
-    _lib.poison_lds(dev)
-    outs = []
-    for _ in range(40):
-        pooled = torch.full((B, 128), float("nan"), device=dev)
-        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None,
-                                              0, _lib.stream_ptr(dev)), "trunk")
-        outs.append(pooled)
-    torch.cuda.synchronize()
-    bad = [i for i, o in enumerate(outs) if not torch.equal(o, outs[-1])]
-    _lib.set_option("trunk_variant", 0)
-    ref = torch.empty((B, 128), device=dev)
-    _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(ref), None, None, None, None, 0, _lib.stream_ptr(dev)), "trunk")
-    err = float((outs[0] - ref).abs().max())
-    print(f"variant {variant}: launches differing from the last: {bad[:8]} ({len(bad)}/40); first launch vs exact-f32 kernel max|d pooled| = {err:.3e}")
-    return 1 if bad or not err < 1e-5 else 0
+    word = m.saturation_word(dev)
+    rc = 0
+    # both builds of the default trunk: flags 0 = range guard by bounds (any weight set), the module's own flags = the build for a
+    # weight set whose fp16 range is proven (AQG_GNN_RANGE_PROVEN; what predict / the engine launch for these weights)
+    for flags in (0, m.gnn_flags(dev)):
+        _lib.set_option("trunk_variant", variant)
+        _lib.poison_lds(dev)
+        outs = []
+        for _ in range(40):
+            pooled = torch.full((B, 128), float("nan"), device=dev)
+            _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None,
+                                                          flags, _lib.ptr(word), _lib.stream_ptr(dev)), "trunk")
+            outs.append(pooled)
+        torch.cuda.synchronize()
+        bad = [i for i, o in enumerate(outs) if not torch.equal(o, outs[-1])]
+        _lib.set_option("trunk_variant", 0)
+        ref = torch.empty((B, 128), device=dev)
+        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(ref), None, None, None, None, 0, _lib.stream_ptr(dev)), "trunk")
+        err = float((outs[0] - ref).abs().max())
+        print(f"variant {variant} flags {flags}: launches differing from the last: {bad[:8]} ({len(bad)}/40); first launch vs exact-f32 kernel max|d pooled| = {err:.3e}; guard word {int(word.item())}")
+        rc |= 1 if bad or not err < 1e-5 or int(word.item()) else 0
+    return rc
 
 
 if __name__ == "__main__":
