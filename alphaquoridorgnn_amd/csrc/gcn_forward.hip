@@ -641,7 +641,8 @@ struct alignas(16) TrunkSmemM {
     alignas(16) float Y[NWV][96];                      // per-wave scratch of the setup: X0[k][f] / sqrt(deg k) of the wave's feature
     alignas(16) unsigned short degv[NWV][NWV == 4 ? 3 : 2][32];   // per wave and block slot: fp16 CQ / deg of the 32 nodes of a k block
     alignas(16) float dinvtab[8];                      // 1 / (81 CQ sqrt(deg)), deg = 1..5: the mean pool's weights, read by (deg - 1) * 4 (set once per workgroup)
-    alignas(16) float dinv1[8];                        // 1 / sqrt(deg): the layer-1 input rows' weights
+    alignas(16) float dinv1[NWV][8];                   // 1 / sqrt(deg): the layer-1 input rows' weights, one copy per wave (written and
+                                                       // read by the same wave: no barrier between kernel start and the first board's setup)
 };
 static_assert(2 * sizeof(TrunkSmemM<8>) <= 160 * 1024, "two 8-wave workgroups per CU");
 
@@ -1437,8 +1438,8 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
         const int t0 = (int)threadIdx.x;
         for (int i = t0; i < (1 + AQG_PREFETCH) * 81 * 2; i += 64 * NWV)
             *reinterpret_cast<unsigned int*>(&sm.G16[0][0][0] + 16 * (i >> 1) + 6 + 8 * (i & 1)) = 0u;
-        if (t0 < 8) { sm.dinvtab[t0] = dinv_of_dm((uint32_t)t0) * (float)(1.0 / (81.0 * CQ)); sm.dinv1[t0] = dinv_of_dm((uint32_t)t0); }
-        __syncthreads();                                          // (dinv1 is read by the first board's input build)
+        if (t0 < 8) sm.dinvtab[t0] = dinv_of_dm((uint32_t)t0) * (float)(1.0 / (81.0 * CQ));      // (first read behind the layer-3 barriers)
+        if ((t0 & 63) < 8) sm.dinv1[t0 >> 6][t0 & 63] = dinv_of_dm((uint32_t)(t0 & 63));           // each wave its own copy: no barrier here
     }
     u32x4 Bf[2][JT][4];
     const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
@@ -1446,7 +1447,7 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
 
     auto decode = [&](uint32_t r0, uint32_t r1, uint64_t& hw, uint64_t& vw, uint32_t& hd) { trunk_decode(fmt, r0, r1, hw, vw, hd); };
     auto build_inputs = [&](int par, uint64_t hw, uint64_t vw, uint32_t hd, int what) {
-        trunk_build_inputs<NWV>(sm.G16[par], sm.AF[par], sm.Y[wave], sm.degv[wave], sm.dinv1, wave, hw, vw, hd, what);
+        trunk_build_inputs<NWV>(sm.G16[par], sm.AF[par], sm.Y[wave], sm.degv[wave], sm.dinv1[wave], wave, hw, vw, hd, what);
     };
 
     AQG_STAMP_DECL
