@@ -10,15 +10,17 @@ from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
 from tools.microbench import synth_states
 dev = _lib.require_gpu("cuda:0"); lib = _lib.load()
 model = GNNNetwork().to(dev).eval(); pk = model.packed_weights(dev)
+flags = int(os.environ.get("AQG_GNN_FLAGS", model.gnn_flags(dev))); word = model.saturation_word(dev)
 variants = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "6,5,4".split(","))]
 sizes = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "480,512,1024,2048,4096,16384,65536".split(","))]
 for B in sizes:
     st = synth_states(B); pooled = torch.empty((B, 128), device=dev)
     policy = torch.empty((B, 209), device=dev); value = torch.empty((B,), device=dev)
+    # the module's own call: guarded entry with this weight set's flags (range guard: proven bound or tracking build)
     def trunk():
-        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, 0, _lib.stream_ptr(dev)), "t")
+        _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, None, None, None, flags, _lib.ptr(word), _lib.stream_ptr(dev)), "t")
     def full():
-        _lib.check(lib.aqg_gcn_forward_boards(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None, _lib.ptr(value), 0, _lib.stream_ptr(dev)), "t")
+        _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None, _lib.ptr(value), flags, _lib.ptr(word), _lib.stream_ptr(dev)), "t")
     res = {}
     for rnd in range(3):
         for v in variants:
