@@ -1868,6 +1868,10 @@ __global__ __launch_bounds__(256, 2) void gcn_heads_mm_kernel(const float* __res
     __shared__ HeadsSmem sm;
     AQG_TRACE_BEGIN
     if (prio) __builtin_amdgcn_s_setprio(1);       // a short latency chain: let it out of the trunk workgroups' way quickly (option "heads_prio")
+#ifdef AQG_HEADS_DELAY      // timing-only probe (tools/ab_trunk.py --bench): the heads launch made AQG_HEADS_DELAY x ~1 us longer, to read
+                            // off how much of a set's step -> trunk -> heads chain ends up in the generation time
+    for (int i = 0; i < AQG_HEADS_DELAY; ++i) __builtin_amdgcn_s_sleep(36);
+#endif
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * 16;
