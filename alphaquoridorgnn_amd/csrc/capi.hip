@@ -63,7 +63,7 @@ const char* aqg_last_error(void) { return g_err; }
 
 int aqg_set_option(const char* name, int value) {
     if (name && !strcmp(name, "trunk_variant")) { if (!(value == 0 || value == 1 || (value >= 3 && value <= 7))) return fail("trunk_variant must be 0, 1, 3, 4, 5, 6 or 7"); g_trunk_variant = value; return 0; }
-    if (name && !strcmp(name, "heads_prio")) { g_heads_prio = value ? 1 : 0; return 0; }
+    if (name && !strcmp(name, "heads_prio")) { g_heads_prio = value < 0 ? 0 : (value > 3 ? 3 : value); return 0; }
     if (name && !strcmp(name, "trunk_prio")) { g_trunk_prio = value < 0 ? -1 : (value & 15); return 0; }
     if (name && !strcmp(name, "trunk_grid")) { g_trunk_grid = value; return 0; }
     if (name && !strcmp(name, "trunk_phase_delay")) { if (value < 0 || value > 4096) return fail("trunk_phase_delay out of range"); g_trunk_phase_delay = value; return 0; }

@@ -1867,7 +1867,9 @@ __global__ __launch_bounds__(256, 2) void gcn_heads_mm_kernel(const float* __res
                                                               int32_t* __restrict__ saturated) {
     __shared__ HeadsSmem sm;
     AQG_TRACE_BEGIN
-    if (prio) __builtin_amdgcn_s_setprio(1);       // a short latency chain: let it out of the trunk workgroups' way quickly (option "heads_prio")
+    // a short latency chain that shares its CUs with other game sets' trunk workgroups: at a higher wave priority it is out of their
+    // way sooner, and a microsecond of it is worth 0.5-0.6 us of every round of the self-play loop (option "heads_prio", 0..3)
+    if (prio == 1) __builtin_amdgcn_s_setprio(1); else if (prio == 2) __builtin_amdgcn_s_setprio(2); else if (prio == 3) __builtin_amdgcn_s_setprio(3);
 #ifdef AQG_HEADS_DELAY      // timing-only probe (tools/ab_trunk.py --bench): the heads launch made AQG_HEADS_DELAY x ~1 us longer, to read
                             // off how much of a set's step -> trunk -> heads chain ends up in the generation time
     for (int i = 0; i < AQG_HEADS_DELAY; ++i) __builtin_amdgcn_s_sleep(36);
@@ -2047,7 +2049,8 @@ AQG_TRACE_SETTER(set_trace_gcn)
 // with benign leftovers, wrong once the LDS held NaN patterns -- tools/cold_launch_check.py poisons the LDS before
 // the first launch of a process to catch exactly this class of bug).
 int g_trunk_variant = 3;
-int g_heads_prio = 0;             // wave priority 1 for the heads kernel (option "heads_prio")
+int g_heads_prio = 3;             // wave priority of the heads kernel (option "heads_prio", 0..3): round 3, same-box runs: 0 -> 1,626 / 1,641 games/s,
+                                  // 1 -> 1,644 / 1,648, 2 -> 1,646, 3 -> 1,657 (profiles/r03_trunk_ab_runs.log)
 int g_trunk_prio = -1;            // wave priorities (bit 0: waves 4-7, bit 1: second-resident workgroups, bit 2: first, bit 3: the two workgroups
                                   // of a CU alternate at priority 1 phase by phase); -1 = by launch size: alternation at >= 1024 boards
                                   // (+2-3 %: 45.3 M boards/s at 4,096, 47.9 M at 65,536; tools/prio_scan.py), none below (no gain at 480 and

@@ -36,8 +36,8 @@ const char* aqg_last_error(void);
 /* tuning knobs: "trunk_variant" 0/1 = exact f32-input MFMA with 1/2 workgroups per CU, 3 = all-MFMA fp16 split trunk
  * (hi*hi + hi*lo + lo*hi: fp32-equivalent products; default = the 8-wave x 2-per-CU form, also selected by 6), 4 / 5 = the
  * 4-wave x 2-per-CU form, 7 = the pair form (one workgroup per CU, two boards per pass: measured slower, kept as evidence); "step_variant" 1/0 = one-load-round MCTS step / round-1 step, "step_fast_depth" = tree depth at which
- * the fast step hands over to memory mode; "trunk_prio" = static wave priorities in the trunk (-1 = by launch size, default); "step_prio" 0..3 / "heads_prio" 0/1 = wave
- * priority of the MCTS step / heads kernels (defaults 1 / 0); "step_waves" = games per step workgroup (4);
+ * the fast step hands over to memory mode; "trunk_prio" = static wave priorities in the trunk (-1 = by launch size, default); "step_prio" / "heads_prio" 0..3 = wave
+ * priority of the MCTS step / heads kernels (defaults 1 / 3); "step_waves" = games per step workgroup (4);
  * "fuse_heads" 1 = heads inside the trunk workgroup (measured slower, default 0); "train_fused" = form of the training step
  * (csrc/gcn_train.hip): 2 (default) one workgroup per position with every contraction in fp16 split precision on the 16-bit
  * matrix pipe (9x9 board; a position whose values leave fp16 range is redone in f32 inside the same launch, counted by
