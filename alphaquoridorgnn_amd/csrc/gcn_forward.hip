@@ -1386,6 +1386,9 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
 #endif
     // The two workgroups resident on a CU run identical phase sequences; a start offset for the second-resident ones
     // (phase_delay x 64 cycles) keeps one on the matrix pipe while the other does vector work.
+#ifdef AQG_TRUNK_DELAY      // timing-only probe, as AQG_HEADS_DELAY: every trunk workgroup AQG_TRUNK_DELAY x ~1 us longer
+    for (int i = 0; i < AQG_TRUNK_DELAY; ++i) __builtin_amdgcn_s_sleep(36);
+#endif
     const int prio_mode = phase_delay >> 16;     // static wave priorities (aqg_set_option("trunk_prio"); chosen by launch size on the host)
     phase_delay &= 0xFFFF;
     for (int i = 0; i < (int)(blockIdx.x >> 8) * phase_delay; ++i) __builtin_amdgcn_s_sleep(1);   // 2nd / 3rd resident: 1x / 2x
