@@ -44,7 +44,8 @@ const char* aqg_last_error(void);
  * aqg_gcn_train_fallbacks), 1 one workgroup per position with f32-input MFMA, 0 the six-launch column-split chain, 3 = 2 with
  * every position sent through the f32 fallback (tests);
  * "trunk_phase_delay" = start offset of the second- / third-resident workgroups in units of 64 cycles, applied to
- * launches of at least "trunk_delay_min_boards" boards; "use_graph" 0/1 = replay
+ * launches of at least "trunk_delay_min_boards" boards; "trunk_grid" = workgroups of a trunk launch (0 = default: min(boards, 512); diagnostics);
+ * "use_graph" 0/1 = replay
  * a move's 3*sims+2 launches as one captured hipGraph when the stream is capturable (default 1); "profile_trunk" 0/1/2 = no event pairs / around trunk launches / around MCTS step launches */
 int aqg_set_option(const char* name, int value);
 /* Measurement aid (bench.py): with option "profile_trunk" = 1 a HIP event pair is recorded around every launch of the

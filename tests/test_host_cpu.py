@@ -403,3 +403,24 @@ def test_static_fp16_range_bound_of_a_weight_set():
         for l in range(3):
             x = np.maximum(og.gcn_conv(x, e, p64[f"gcn_layers.{l}.lin.weight"], p64[f"gcn_layers.{l}.bias"]), 0.0)
             assert x.max() <= bounds[l]
+
+
+def test_set_option_names_ranges_and_errors():
+    """aqg_set_option is host code: every documented knob is accepted, out-of-range values and unknown names are refused with a
+    message in aqg_last_error (no GPU call involved)."""
+    from alphaquoridorgnn_amd import _lib
+    lib = _lib.load()
+    defaults = {"trunk_variant": 3, "heads_prio": 3, "trunk_prio": -1, "trunk_grid": 0, "trunk_phase_delay": 100, "trunk_delay_min_boards": 2048,
+                "step_prio": 1, "step_waves": 4, "step_variant": 1, "step_fast_depth": None, "fuse_heads": 0, "train_fused": 2, "use_graph": 1,
+                "profile_trunk": 0}
+    header = open(os.path.join(REPO, "include", "aqgnn.h")).read()
+    for name, value in defaults.items():
+        assert f'"{name}"' in header, f"{name} is not documented in include/aqgnn.h"
+        if value is not None:
+            assert lib.aqg_set_option(name.encode(), value) == 0, name
+    for name, bad in (("trunk_variant", 2), ("trunk_variant", 8), ("trunk_phase_delay", -1), ("step_fast_depth", 62), ("train_fused", 4)):
+        assert lib.aqg_set_option(name.encode(), bad) != 0, (name, bad)
+        assert lib.aqg_last_error()
+    assert lib.aqg_set_option(b"no_such_option", 1) != 0 and b"no_such_option" in lib.aqg_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.set_option("no_such_option", 1)
