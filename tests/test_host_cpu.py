@@ -414,8 +414,10 @@ def test_set_option_names_ranges_and_errors():
                 "step_prio": 1, "step_waves": 4, "step_variant": 1, "step_fast_depth": None, "fuse_heads": 0, "train_fused": 2, "use_graph": 1,
                 "profile_trunk": 0}
     header = open(os.path.join(REPO, "include", "aqgnn.h")).read()
+    integration = open(os.path.join(REPO, "INTEGRATION.md")).read()
     for name, value in defaults.items():
         assert f'"{name}"' in header, f"{name} is not documented in include/aqgnn.h"
+        assert f"`{name}`" in integration, f"{name} is not listed in INTEGRATION.md"
         if value is not None:
             assert lib.aqg_set_option(name.encode(), value) == 0, name
     for name, bad in (("trunk_variant", 2), ("trunk_variant", 8), ("trunk_phase_delay", -1), ("step_fast_depth", 62), ("train_fused", 4)):
