@@ -1585,3 +1585,10 @@ def test_generation_replays_on_exact_kernels_after_range_guard(dev):
     ms.sets[1].t["counters"][5] = 1
     c = ms.play_generation()
     assert all(e.e.gnn_flags == _lib.GNN_EXACT_F32 for e in ms.sets) and c["finished"] == 8 and c["gnn_saturated"] == 0
+
+
+@pytest.mark.gpu
+def test_graft_entry_smoke():
+    """The driver's smoke step (legal mask, GNN forward, MCTS, a tiny generation against the oracle) stays runnable."""
+    import __graft_entry__
+    __graft_entry__.smoke()
