@@ -13,7 +13,6 @@ extern int g_trunk_grid;
 extern int g_trunk_phase_delay;
 extern int g_trunk_delay_min_boards;
 extern int g_use_graph;
-extern int g_fuse_heads;
 extern int g_step_variant;
 extern int g_step_waves;
 extern int g_step_prio;
@@ -62,7 +61,7 @@ int aqg_abi_version(void) { return AQG_ABI_VERSION; }
 const char* aqg_last_error(void) { return g_err; }
 
 int aqg_set_option(const char* name, int value) {
-    if (name && !strcmp(name, "trunk_variant")) { if (!(value == 0 || value == 1 || (value >= 3 && value <= 7))) return fail("trunk_variant must be 0, 1, 3, 4, 5, 6 or 7"); g_trunk_variant = value; return 0; }
+    if (name && !strcmp(name, "trunk_variant")) { if (!(value == 0 || value == 1 || value == 3 || value == 6)) return fail("trunk_variant must be 0, 1, 3 or 6"); g_trunk_variant = value; return 0; }
     if (name && !strcmp(name, "heads_prio")) { g_heads_prio = value < 0 ? 0 : (value > 3 ? 3 : value); return 0; }
     if (name && !strcmp(name, "trunk_prio")) { g_trunk_prio = value < 0 ? -1 : (value & 15); return 0; }
     if (name && !strcmp(name, "trunk_grid")) { g_trunk_grid = value; return 0; }
@@ -72,7 +71,6 @@ int aqg_set_option(const char* name, int value) {
     if (name && !strcmp(name, "step_waves")) { g_step_waves = value; return 0; }
     if (name && !strcmp(name, "step_variant")) { g_step_variant = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "step_fast_depth")) { if (value < 0 || value > 61) return fail("step_fast_depth must be 0..61"); g_step_fast_depth = value; return 0; }
-    if (name && !strcmp(name, "fuse_heads")) { g_fuse_heads = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "train_fused")) { if (value < 0 || value > 3) return fail("train_fused: 0..3"); g_train_fused = value; return 0; }
     if (name && !strcmp(name, "use_graph")) { g_use_graph = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "profile_trunk")) { g_profile_trunk = (value == 1 || value == 2) ? value : 0; return 0; }   // 1 = trunk launches, 2 = step launches

@@ -198,8 +198,17 @@ int pack_weights_host(int N, const float* const* t, float* out) {
         for (int deg = 1; deg <= 5; ++deg)
             for (int f = 0; f < HID; ++f) tbmax = std::max(tbmax, std::fabs((double)out[PackedLayout::TB + ((size_t)1 * 5 + (deg - 1)) * HID + f]));
         const double t2 = (65504.0 - tbmax) / 2.07;
-        out[PackedLayout::GUARD + 0] = (float)(t2 > 0.0 && t2 == t2 ? t2 : 0.0);      // (NaN / negative: every board is reported)
-        out[PackedLayout::GUARD + 1] = 65504.0f;
+        // A weight whose fp16 hi half is not finite (|W| / CQ >= 65504 rounds to inf, or W is inf / NaN) makes every product of its
+        // column inf - inf or 0 x inf = NaN, and the float maxima of the tracking build skip NaNs (v_max3_f32 returns the non-NaN
+        // operand): such a set gets NEGATIVE thresholds, which no maximum satisfies -- every board is reported and the host serves
+        // the set with the exact kernels (include/aqgnn.h promises "inf / NaN included").  The same for a NaN / negative bound.
+        bool hi_finite = true;
+        auto hi_ok = [](double x) { const float h = (float)(_Float16)(float)x; return h == h && std::fabs(h) <= 65504.0f; };
+        for (int i = 0; i < HID * F; ++i) hi_finite = hi_finite && hi_ok(CQ * (double)t[0][i]);
+        for (int i = 0; i < HID * HID; ++i) hi_finite = hi_finite && hi_ok((double)t[2][i] / CQ) && hi_ok((double)t[4][i] / CQ);
+        const bool bound_ok = t2 > 0.0 && t2 == t2;
+        out[PackedLayout::GUARD + 0] = (hi_finite && bound_ok) ? (float)t2 : -1.0f;
+        out[PackedLayout::GUARD + 1] = hi_finite ? 65504.0f : -1.0f;
         out[PackedLayout::GUARD + 2] = out[PackedLayout::GUARD + 3] = 0.f;
     }
     for (int u = 0; u < HID / 2; ++u)
@@ -610,41 +619,29 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gcn_trunk_boards_kernel(const
 //    the plane image (or, for the last layer, the per-lane partial of the mean pool).  No parking of f32 tiles in
 //    LDS, no VALU gather, no separate layer-1 gather: layer 1 is  X0 W1  (one MFMA per tile: the six features and
 //    the hi/lo split of W1 share one 32-deep k block, X0 is exact in fp16) followed by the same aggregation.
-// Per wave and board: 12 + 2 x 144 MFMAs for the linear maps + 3 x 40 for the aggregation.
+// Per wave and board: 6 + 2 x 72 MFMAs for layer 1 and the linear maps + 2 x 20 for the aggregations.
 // =============================================================================================
-// Where a board's inputs are built (developer switches, A/B'd with tools/ab_trunk.py):
-//   AQG_PREFETCH 1: board b + 1's inputs are built under board b's layer 3 into the other buffers (no setup phase per board);
-//                0: at the top of each board.   AQG_AF_AT 0: adjacency fragments together with the G' rows; 1: after layer 1;
-//                2: after the layer-2 linear map, in front of the barrier its early waves wait at anyway.
-#ifndef AQG_PREFETCH
-#define AQG_PREFETCH 0
-#endif
-// timing-only ablations (tools/ab_trunk.py; wrong results by construction, never shipped): AQG_ABL_BAR drops the per-board
-// barriers, AQG_ABL_SETUP builds a workgroup's inputs for its first board only (AQG_ABL_SETUP0: for none), AQG_ABL_EPI drops the plane stores of the
-// epilogues, AQG_ABL_LDSA the A-fragment reads of the linear maps, AQG_ABL_LIN / AQG_ABL_AGG the MFMAs
-#ifdef AQG_ABL_BAR
-#define AQG_BOARD_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#else
+// One 8-wave workgroup walks boards (persistent grid, two workgroups per CU); a wave owns one 16-column feature tile for all 81 nodes.
+// Per board: record decode + bias offsets, the layer-1 input rows G' (built at the top), layer 1, the adjacency fragments (built behind
+// layer 1), linear map / aggregation of layers 2 and 3, mean pool -- four workgroup barriers.  (Forms measured slower and removed in
+// round 4 -- a 4-wave form, a one-workgroup-per-CU pair form, per-board VALU heads, next-board prefetch under layer 3 -- and the
+// timing-only ablation switches that priced this kernel's parts are in the history: git show 8ccbea1:alphaquoridorgnn_amd/csrc/gcn_forward.hip,
+// results in profiles/r03_trunk_ablation.log / r03_trunk_ab_runs.log.)
+constexpr int NWV = 8;                                 // waves per trunk workgroup
 #define AQG_BOARD_BARRIER() __syncthreads()
-#endif
-#ifndef AQG_AF_AT
-#define AQG_AF_AT 1
-#endif
-template <int NWV>
 struct alignas(16) TrunkSmemM {
     alignas(16) unsigned char P[2][PPLANE];            // fp16 hi / lo planes of the activation image [node][feature] (scale CQ / D^-1/2)
-    alignas(16) unsigned int AF[1 + AQG_PREFETCH][AF_BLOCKS][64][4];   // B fragments of (A + I) diag(CQ / deg) of a board (fp16, exact); [board parity] when prefetching
+    alignas(16) unsigned int AF[AF_BLOCKS][64][4];     // B fragments of (A + I) diag(CQ / deg) of the board (fp16, exact)
     // layer-1 input, aggregated FIRST: G'[n][f] = sum over the closed neighbourhood k of n of X0[k][f] / sqrt(deg k), as fp16
-    // hi[0..7] | lo[8..15] per node (6 features used, slots 6, 7 stay zero); two buffers: board parity (the next board's rows are
-    // written while this board's layers 2, 3 run)
-    alignas(16) unsigned short G16[1 + AQG_PREFETCH][81][16];
+    // hi[0..7] | lo[8..15] per node (6 features used, slots 6, 7 stay zero)
+    alignas(16) unsigned short G16[81][16];
     alignas(16) float Y[NWV][96];                      // per-wave scratch of the setup: X0[k][f] / sqrt(deg k) of the wave's feature
-    alignas(16) unsigned short degv[NWV][NWV == 4 ? 3 : 2][32];   // per wave and block slot: fp16 CQ / deg of the 32 nodes of a k block
+    alignas(16) unsigned short degv[NWV][2][32];       // per wave and block slot: fp16 CQ / deg of the 32 nodes of a k block
     alignas(16) float dinvtab[8];                      // 1 / (81 CQ sqrt(deg)), deg = 1..5: the mean pool's weights, read by (deg - 1) * 4 (set once per workgroup)
     alignas(16) float dinv1[NWV][8];                   // 1 / sqrt(deg): the layer-1 input rows' weights, one copy per wave (written and
                                                        // read by the same wave: no barrier between kernel start and the first board's setup)
 };
-static_assert(2 * sizeof(TrunkSmemM<8>) <= 160 * 1024, "two 8-wave workgroups per CU");
+static_assert(2 * sizeof(TrunkSmemM) <= 160 * 1024, "two 8-wave workgroups per CU");
 
 __device__ __forceinline__ float row16_sum(float x) {     // sum over the 16 lanes of a DPP row, result in every lane
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));   // row_ror:8
@@ -705,31 +702,14 @@ __device__ __forceinline__ float relu_f(float x) { return __builtin_bit_cast(flo
 
 // Runtime fp16-range guard.  The split kernels are fp32-equivalent only while every value they store as fp16 pairs stays inside
 // fp16 range: the post-ReLU activations (clamped at 65504 instead of overflowing) and the linear maps' outputs (converted as they
-// are split).  Every epilogue tracks the PRE-clamp bit patterns of what it stores (track_range): that sees an activation beyond
-// the range, and it sees a linear-map output beyond it as well -- such a z becomes +-inf in its hi half (and -+inf in its lo
-// half), every banded adjacency block multiplies it by exact zeros, and 0 x inf = NaN lands in the accumulators of its node
-// tile (layer 3's lands in the pooled row, which the heads kernel checks).  A launch that met such a value ORs 1 into the caller's `saturated` word: the host then serves the
-// weight set with the exact f32-input kernels (pv_network_gnn / engine).  The reference's fp32 has no such cliff
-// (pv_network_gnn.py:53-64).  tests/test_gpu_parity.py::test_gnn_runtime_saturation_signal drives all three cases.
-constexpr int F16_MAX_BITS = 0x477FE000;      // 65504.0f
-// As SIGNED integers the patterns of the positive floats order like the floats and lie above every negative float: the signed
-// maximum exceeds 65504's pattern exactly when a value (or +inf, or a NaN with a clear sign bit) does.  As UNSIGNED integers -inf
-// and the NaNs with the sign bit set lie above everything else: 0 x (-inf) in an adjacency block gives such a NaN on this
-// hardware, and relu maps it to 0 without a trace.  Two v_max3 per four values each.
-__device__ __forceinline__ int float_bits(float x) { return __builtin_bit_cast(int, x); }
-__device__ __forceinline__ void track_range(const f32x4 v, int& imax, unsigned int& umax) {
-#ifdef AQG_NO_RANGE_GUARD      // timing-only build (tools/ab_trunk.py): what the guard costs
-    return;
-#endif
-    // (through scalar parameters: __builtin_bit_cast applied to a vector ELEMENT expression -- bit_cast(int, v[1]) -- read element 0
-    //  for every index with hipcc 7.2, and the guard watched one value in four; tools/range_guard_probe.py pins the fixed form)
-    const int i0 = float_bits(v[0]), i1 = float_bits(v[1]), i2 = float_bits(v[2]), i3 = float_bits(v[3]);
-    imax = max(max(i0, i1), imax);
-    imax = max(max(i2, i3), imax);
-    umax = max(max((unsigned int)i0, (unsigned int)i1), umax);
-    umax = max(max((unsigned int)i2, (unsigned int)i3), umax);
-}
-__device__ __forceinline__ bool out_of_range(int imax, unsigned int umax) { return imax > F16_MAX_BITS || umax >= 0xFF800000u; }
+// are split).  Where a static bound over all inputs proves that (AQG_GNN_RANGE_PROVEN) only the records' wall counts are checked;
+// otherwise layer 1's pre-clamp outputs are bounded by a float maximum, the linear maps' outputs U by a float maximum of |U| against
+// PackedLayout::GUARD (layer 2's aggregate is then bounded analytically; layer 3's lands in the pooled row, which the heads kernel
+// checks).  A launch that met such a value ORs 1 into the caller's `saturated` word: the host then serves the weight set with the exact
+// f32-input kernels (pv_network_gnn / engine).  The reference's fp32 has no such cliff (pv_network_gnn.py:53-64).
+// tests/test_gpu_parity.py::test_gnn_runtime_saturation_signal / test_gnn_range_guard_watches_every_feature drive it.
+// (__builtin_bit_cast applied to a vector ELEMENT expression -- bit_cast(int, v[1]) -- read element 0 for every index with hipcc 7.2:
+//  the first, per-value form of this guard watched one value in four.  Take the element into a scalar first.)
 __device__ __forceinline__ void report_saturation(bool lane_saw_it, int32_t* __restrict__ saturated) {
     if (saturated && __builtin_amdgcn_ballot_w64(lane_saw_it) != 0) {            // wave-uniform, practically never taken
         int l;
@@ -738,28 +718,19 @@ __device__ __forceinline__ void report_saturation(bool lane_saw_it, int32_t* __r
     }
 }
 
-// A wave owns JT 16-column feature tiles: JT = 2 -> 4 waves per board, JT = 1 -> 8 waves per board.
 // fp16 planes of four consecutive features of one node: hi (11 bits) + lo (next 11 bits) = 22 mantissa bits
-template <class SM>
-__device__ __forceinline__ void store_split4(SM& sm, int off, const f32x4 v) {
-#ifdef AQG_ABL_EPI
-    asm volatile("" :: "v"(v), "v"(off));
-#else
+__device__ __forceinline__ void store_split4(TrunkSmemM& sm, int off, const f32x4 v) {
     const unsigned int h01 = cvt_pk_f16(v[0], v[1]), h23 = cvt_pk_f16(v[2], v[3]);
     *reinterpret_cast<u32x2*>(&sm.P[0][off]) = (u32x2){h01, h23};
     *reinterpret_cast<u32x2*>(&sm.P[1][off]) = (u32x2){lo_pair(h01, v[0], v[1]), lo_pair(h23, v[2], v[3])};
-#endif
 }
 
-template <int JT>
-__device__ __forceinline__ void load_bfrag_mm(u32x4 (&Bf)[2][JT][4], __amdgpu_buffer_rsrc_t rs, size_t region, int wave, int lane) {
-    const int base = (int)(region * sizeof(float)) + wave * (JT * 4 * 64 * 16);
+__device__ __forceinline__ void load_bfrag_mm(u32x4 (&Bf)[2][4], __amdgpu_buffer_rsrc_t rs, size_t region, int wave, int lane) {
+    const int base = (int)(region * sizeof(float)) + wave * (4 * 64 * 16);
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-        for (int j = 0; j < JT; ++j)
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) Bf[pl][j][kb] = load_frag16(rs, lane * 16, base + (pl * (8 * 4 * 64) + (j * 4 + kb) * 64) * 16);
+        for (int kb = 0; kb < 4; ++kb) Bf[pl][kb] = load_frag16(rs, lane * 16, base + (pl * (8 * 4 * 64) + kb * 64) * 16);
 }
 
 // fp16 hi / lo aggregation fragments of one finished 16-node tile m of U (accumulator layout: lane = feature column, 4
@@ -789,91 +760,56 @@ __device__ __forceinline__ void split_tile_piece(const f32x4 z, int m, int piece
 // U = Q W~ for this wave's columns: six 16-row tiles (tile 5 = row 80 repeated) x four 32-deep k blocks, A fragments
 // double-buffered from the planes, three fp16 terms per block (smallest first).  The fp16 split of tile m - 1 (six vector
 // instructions per feature tile) is issued between the MFMA groups of tile m: it costs no time of its own.
-// mid() is called in front of step AQG_BIAS_STEP: the kernel requests the aggregation's bias rows there (24 registers that need
-// not be alive through the first steps of the map -- room for a deeper fragment ring at the 128-register cap).
-#ifndef AQG_BIAS_STEP
-#define AQG_BIAS_STEP 0
-#endif
+// mid() is called in front of step 0: the kernel requests the aggregation's bias rows there.
 struct NoMid { __device__ __forceinline__ void operator()() const {} };
-template <int JT, class SM, class Mid = NoMid>
-__device__ __forceinline__ void linear_split(const SM& sm, const u32x4 (&Bf)[2][JT][4], int lane, u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], Mid mid = Mid(),
+template <class Mid = NoMid>
+__device__ __forceinline__ void linear_split(const TrunkSmemM& sm, const u32x4 (&Bf)[2][4], int lane, u32x4 (&zh)[3], u32x4 (&zl)[3], Mid mid = Mid(),
                                              float* zmax = nullptr) {
     const int c = lane & 15, q = lane >> 4;
-    // the fragments of step s + AQG_LIN_AHEAD are requested while step s multiplies (a ring of that many register pairs).  One step
-    // ahead is enough with four waves per SIMD: 2 / 3 steps measured 48.0 / 45.4 M boards/s against 48.4 at 4,096 boards
-    // (tools/ab_trunk.py; 3 spills), whatever AQG_BIAS_STEP frees -- and the -26 % of the AQG_ABL_LDSA row is its constant operands'
-    // clock (DVFS), not these reads.
-#ifndef AQG_LIN_AHEAD
-#define AQG_LIN_AHEAD 1
-#endif
-    constexpr int D = AQG_LIN_AHEAD;
-    u32x4 ring[D + 1][2];
+    // the fragments of step s + 1 are requested while step s multiplies (two register pairs).  One step ahead is enough with four
+    // waves per SIMD: rings 2 / 3 steps deep measured 48.0 / 45.4 M boards/s against 48.4 at 4,096 boards (round 3).
+    u32x4 ring[2][2];
     auto frag_off = [&](int step) -> int {                  // step = m*4 + kb
         const int m = step >> 2, kb = step & 3;
         const int row = (m < 5) ? 16 * m + c : 80;
         return plane_off(row, 4 * kb + q);
     };
     auto request = [&](int step) {
-#ifdef AQG_ABL_LDSA
-        ring[step % (D + 1)][0] = ring[(step + D) % (D + 1)][1]; ring[step % (D + 1)][1] = ring[(step + D) % (D + 1)][0];
-#else
         const int o = frag_off(step);
-        ring[step % (D + 1)][0] = *reinterpret_cast<const u32x4*>(&sm.P[0][o]);
-        ring[step % (D + 1)][1] = *reinterpret_cast<const u32x4*>(&sm.P[1][o]);
-#endif
+        ring[step & 1][0] = *reinterpret_cast<const u32x4*>(&sm.P[0][o]);
+        ring[step & 1][1] = *reinterpret_cast<const u32x4*>(&sm.P[1][o]);
     };
-    {
-        const int o = frag_off(0);
-        ring[0][0] = *reinterpret_cast<const u32x4*>(&sm.P[0][o]);
-        ring[0][1] = *reinterpret_cast<const u32x4*>(&sm.P[1][o]);
-    }
-#pragma unroll
-    for (int i = 1; i < D; ++i) request(i);
-    f32x4 acc[JT], done[JT];
+    request(0);
+    f32x4 acc, done;
 #pragma unroll
     for (int step = 0; step < 24; ++step) {
         const int m = step >> 2, kb = step & 3;
-        if (step == AQG_BIAS_STEP) mid();
-        if (step + D < 24) request(step + D);
+        if (step == 0) mid();
+        if (step + 1 < 24) request(step + 1);
         __builtin_amdgcn_sched_barrier(0);
-        const u32x4 hi = ring[step % (D + 1)][0], lo = ring[step % (D + 1)][1];
-#pragma unroll
-        for (int j = 0; j < JT; ++j) {
-            f32x4 a = kb == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[j];
-#ifdef AQG_ABL_LIN     // timing-only ablation (tools/ab_trunk.py): the linear map's MFMAs removed, its LDS reads and splits kept alive
-            asm volatile("" : "+v"(a) : "v"(hi), "v"(lo), "v"(Bf[0][j][kb]), "v"(Bf[1][j][kb]));
-#else
-            a = mfma_f16(lo, Bf[0][j][kb], a);
-            a = mfma_f16(hi, Bf[1][j][kb], a);
-            a = mfma_f16(hi, Bf[0][j][kb], a);
-#endif
-            acc[j] = a;
-            if (m > 0 && kb < 3) split_tile_piece(done[j], m - 1, kb, zh[j], zl[j], zmax);
-        }
+        const u32x4 hi = ring[step & 1][0], lo = ring[step & 1][1];
+        f32x4 a = kb == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc;
+        a = mfma_f16(lo, Bf[0][kb], a);
+        a = mfma_f16(hi, Bf[1][kb], a);
+        a = mfma_f16(hi, Bf[0][kb], a);
+        acc = a;
+        if (m > 0 && kb < 3) split_tile_piece(done, m - 1, kb, zh, zl, zmax);
         __builtin_amdgcn_sched_barrier(0);
-        if (kb == 3) {
-#pragma unroll
-            for (int j = 0; j < JT; ++j) done[j] = acc[j];
-        }
+        if (kb == 3) done = acc;
     }
 #pragma unroll
-    for (int j = 0; j < JT; ++j)
-#pragma unroll
-        for (int piece = 0; piece < 3; ++piece) split_tile_piece(done[j], 5, piece, zh[j], zl[j], zmax);
+    for (int piece = 0; piece < 3; ++piece) split_tile_piece(done, 5, piece, zh, zl, zmax);
 }
 
-// The aggregation accumulators start from the bias: out[nt][j] = TB[layer][deg(node) - 1][this lane's 4 features] = CQ b sqrt(deg),
+// The aggregation accumulators start from the bias: out[nt] = TB[layer][deg(node) - 1][this lane's 4 features] = CQ b sqrt(deg),
 // so that relu(out) IS the next plane image -- no multiply, no add on the vector unit.  `toff` packs (deg - 1) * 512 + 16 q per
 // node tile of this lane, 16 bits each.  Requested a whole phase ahead of their use (before the linear map).
-template <int JT>
-__device__ __forceinline__ void request_bias(f32x4 (&out)[6][JT], __amdgpu_buffer_rsrc_t rs, int layer, const int (&toff)[3], int wave) {
+__device__ __forceinline__ void request_bias(f32x4 (&out)[6], __amdgpu_buffer_rsrc_t rs, int layer, const int (&toff)[3], int wave) {
 #pragma unroll
-    for (int j = 0; j < JT; ++j)
-#pragma unroll
-        for (int nt = 0; nt < 6; ++nt) {
-            const int vo = (nt & 1) ? (int)((unsigned)toff[nt >> 1] >> 16) : (toff[nt >> 1] & 0xFFFF);
-            out[nt][j] = __builtin_bit_cast(f32x4, load_frag16(rs, vo, (int)((PackedLayout::TB + (size_t)layer * 5 * HID) * sizeof(float)) + 64 * (JT * wave + j)));
-        }
+    for (int nt = 0; nt < 6; ++nt) {
+        const int vo = (nt & 1) ? (int)((unsigned)toff[nt >> 1] >> 16) : (toff[nt >> 1] & 0xFFFF);
+        out[nt] = __builtin_bit_cast(f32x4, load_frag16(rs, vo, (int)((PackedLayout::TB + (size_t)layer * 5 * HID) * sizeof(float)) + 64 * wave));
+    }
 }
 
 // Aggregation + epilogue, node tile by node tile:  V^T = U^T (A + I) diag(CQ / deg) on top of the bias rows, then
@@ -881,25 +817,19 @@ __device__ __forceinline__ void request_bias(f32x4 (&out)[6][JT], __amdgpu_buffe
 // The blocks of a node tile are consecutive (a dependent 16x16x32 chain issues at the full rate), so tile nt is complete while
 // tile nt + 1 is still on the matrix pipe: its relu / split / stores are vector and LDS work issued under those MFMAs.
 // (No plane byte is read here: the caller has passed the barrier behind the linear map, the stores are free to go.)
-// TRACK: 0 = no range check here; 1 = every value's bit pattern (track_range); 2 = none here either: the caller has bounded the
-// aggregate by the linear map's output (GUARD_MODE 2 of the kernel)
-template <int JT, bool LAST, int TRACK = 1, class SM>
-__device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)[AF_BLOCKS][64][4], u32x4 (&zh)[JT][3], u32x4 (&zl)[JT][3], f32x4 (&out)[6][JT], int wave, int lane,
-                                                const int (&toff)[3], __amdgpu_buffer_rsrc_t pooled_rs, int pooled_soff, int32_t* __restrict__ saturated,
-                                                float* pooled_lds = nullptr) {
-    constexpr int AHEAD = 3;
-    int imax = 0;                                              // fp16-range guard: largest pre-clamp bit pattern, signed ...
-    unsigned int umax = 0u;                                    // ... and unsigned (see track_range)                                   // adjacency fragments in flight (4 registers each)
+// No range check here: the caller has bounded layer 2's aggregate by its linear map's output (or the weight set's range is proven),
+// layer 3's aggregate is never split (the heads check the pooled row).
+template <bool LAST>
+__device__ __forceinline__ void aggregate_store(TrunkSmemM& sm, const unsigned int (&AF)[AF_BLOCKS][64][4], u32x4 (&zh)[3], u32x4 (&zl)[3], f32x4 (&out)[6], int wave, int lane,
+                                                const int (&toff)[3], __amdgpu_buffer_rsrc_t pooled_rs, int pooled_soff) {
+    constexpr int AHEAD = 3;                                   // adjacency fragments in flight (4 registers each)
     const int c = lane & 15, q = lane >> 4;
-    const int col0 = 16 * JT * wave + 4 * q;
+    const int col0 = 16 * wave + 4 * q;
     u32x4 af[AF_BLOCKS];
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i) af[i] = *reinterpret_cast<const u32x4*>(&AF[i][lane][0]);
-#pragma unroll
-    for (int j = 0; j < JT; ++j) split_fence(zl[j][0], zl[j][1], zl[j][2]);
-    f32x4 sum[JT];
-#pragma unroll
-    for (int j = 0; j < JT; ++j) sum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    split_fence(zl[0], zl[1], zl[2]);
+    f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto epilogue = [&](int nt) {
         const int node = 16 * nt + c;
         const bool live = (nt < 5) || (c == 0);                              // node < 81
@@ -907,26 +837,18 @@ __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)
         // deg - 1 sits above the row offset's 9 bits (and the 16 q below them leave bits 7, 8 clear): bits 7..11 = (deg - 1) * 4, the byte
         // offset into the 1 / sqrt(deg) table -- one v_bfe + one ds_read where the select chain took nine instructions per node tile
         if (LAST) dn = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(sm.dinvtab) + (((unsigned)toff[nt >> 1] >> (7 + 16 * (nt & 1))) & 0x1Cu));
+        f32x4 v = out[nt];
+        if (LAST) {
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
-            f32x4 v = out[nt][j];
-            if (LAST) {
-                if (TRACK == 1 && live) track_range(v, imax, umax); // (only inf / NaN matter here: the pooled row is f32, the heads check its range)
+            for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
+            if (live) sum += v * dn;
+        } else {
+            // relu, saturating at the largest finite fp16: an overflowing activation stays a (wrong) finite number instead of
+            // becoming inf - inf = NaN that the next relu would silently turn into 0 (it has been REPORTED by the caller's bound on
+            // the linear map's output: the host then serves the weight set with the exact-f32 kernels)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
-#ifndef AQG_ABL_POOL      // timing-only ablation (tools/ab_trunk.py): the mean pool's arithmetic removed
-                if (live) sum[j] += v * dn;
-#endif
-            } else {
-                // relu, saturating at the largest finite fp16: an overflowing activation stays a (wrong) finite number
-                // instead of becoming inf - inf = NaN that the next relu would silently turn into 0 -- and is REPORTED (imax):
-                // the host then serves the weight set with the exact-f32 kernels (and checks every set on calibration boards
-                // before it trusts this kernel at all, pv_network_gnn.packed_weights).
-                if (TRACK == 1 && live) track_range(v, imax, umax);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = relu_sat16(v[e]);
-                if (live) store_split4(sm, plane_off(node, (col0 + 16 * j) >> 3) + ((2 * (col0 + 16 * j)) & 15), v);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = relu_sat16(v[e]);
+            if (live) store_split4(sm, plane_off(node, col0 >> 3) + ((2 * col0) & 15), v);
         }
     };
     // blocks are numbered in node-tile order already: kb = {0,0,1,0,1,1,2,1,2,2}, nt = {0,1,1,2,2,3,3,4,4,5}
@@ -934,36 +856,19 @@ __device__ __forceinline__ void aggregate_store(SM& sm, const unsigned int (&AF)
     for (int blk = 0; blk < AF_BLOCKS; ++blk) {
         const int kb = af_kb(blk), nt = af_nt(blk);
         if (blk + AHEAD < AF_BLOCKS) af[blk + AHEAD] = *reinterpret_cast<const u32x4*>(&AF[blk + AHEAD][lane][0]);
-#pragma unroll
-        for (int j = 0; j < JT; ++j) {
-#ifdef AQG_ABL_AGG     // timing-only ablation: the aggregation's MFMAs removed
-            asm volatile("" : "+v"(out[nt][j]) : "v"(zl[j][kb]), "v"(zh[j][kb]), "v"(af[blk]));
-#else
-            out[nt][j] = mfma_f16(zl[j][kb], af[blk], out[nt][j]);
-            out[nt][j] = mfma_f16(zh[j][kb], af[blk], out[nt][j]);
-#endif
-        }
+        out[nt] = mfma_f16(zl[kb], af[blk], out[nt]);
+        out[nt] = mfma_f16(zh[kb], af[blk], out[nt]);
         // tile nt - 1 was finished by the previous block(s): its epilogue goes out under this tile's MFMAs
         if (nt > 0 && (blk + 1 == AF_BLOCKS || af_nt(blk + 1) != nt)) epilogue(nt - 1);
     }
     epilogue(5);
-    if (TRACK == 1) report_saturation(LAST ? (imax >= 0x7F800000 || umax >= 0xFF800000u) : out_of_range(imax, umax), saturated);
     if (LAST) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const int col0 = 16 * JT * wave + 4 * (ln >> 4);
-#pragma unroll
-        for (int j = 0; j < JT; ++j) {
-            f32x4 t;
-#ifdef AQG_ABL_POOL
-            t = sum[j];
-#else
-            t = row16_sum4(sum[j]);                                              // (the table's entries carry the 1 / (81 CQ) of the mean)
-#endif
-            // (buffer store off an SGPR descriptor + scalar row offset: no 64-bit address registers alive across the board loop)
-            if (c == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), pooled_rs, (col0 + 16 * j) * 4, pooled_soff, 0);
-            if (pooled_lds && c == 0) *reinterpret_cast<f32x4*>(pooled_lds + col0 + 16 * j) = t;
-        }
+        const int col0 = 16 * wave + 4 * (ln >> 4);
+        const f32x4 t = row16_sum4(sum);                                  // (the table's entries carry the 1 / (81 CQ) of the mean)
+        // (buffer store off an SGPR descriptor + scalar row offset: no 64-bit address registers alive across the board loop)
+        if (c == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), pooled_rs, col0 * 4, pooled_soff, 0);
     }
 }
 
@@ -996,163 +901,37 @@ __device__ __forceinline__ float lane_sel(uint64_t m, float a) {
 // rows of G' (lane = node; k-slots of q = 0 / 2 read the hi half, q = 1 the lo half, q = 3 meets zero weight slots), accumulated on
 // the bias rows.  The result already has the store layout (lane = node, 4 consecutive features): relu, fp16 split, plane stores.
 // 6 MFMAs per wave and feature tile where the linear-first form needed 6 + 20 (X0 W1, then the 128-wide banded aggregation).
-template <int JT, int TRACK = 1, class SM>
-__device__ __forceinline__ void layer1_store(SM& sm, const unsigned short (&G)[81][16], const u32x4 (&w1f)[JT], f32x4 (&out)[6][JT],
+template <int TRACK>
+__device__ __forceinline__ void layer1_store(TrunkSmemM& sm, const unsigned short (&G)[81][16], const u32x4 &w1f, f32x4 (&out)[6],
                                              int wave, int lane, int32_t* __restrict__ saturated) {
     const int c = lane & 15, q = lane >> 4;
-    int imax = 0;
-    unsigned int umax = 0u;
     float fmx = 0.f;
-    const int col0 = 16 * JT * wave + 4 * q;
+    const int col0 = 16 * wave + 4 * q;
     u32x4 gf[6];
 #pragma unroll
     for (int nt = 0; nt < 6; ++nt) gf[nt] = *reinterpret_cast<const u32x4*>(&G[nt < 5 ? 16 * nt + c : 80][8 * (q & 1)]);
 #pragma unroll
-    for (int nt = 0; nt < 6; ++nt)
-#pragma unroll
-        for (int j = 0; j < JT; ++j) out[nt][j] = mfma_f16(w1f[j], gf[nt], out[nt][j]);
+    for (int nt = 0; nt < 6; ++nt) out[nt] = mfma_f16(w1f, gf[nt], out[nt]);
 #pragma unroll
     for (int nt = 0; nt < 6; ++nt) {
         const int node = 16 * nt + c;
         const bool live = (nt < 5) || (c == 0);                              // node < 81
+        f32x4 v = out[nt];
+        // mode 2: the pre-clamp values are finite here (finite weights times bounded layer-1 rows: no inf, no NaN) and only a
+        // POSITIVE excursion is clamped, so the largest value is all there is to watch -- a plain float maximum, two values per
+        // instruction (the first reader of these matrix-pipe results is the compiler-visible v_med3 below: the maxima sit behind it)
+        f32x4 w = v;
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
-            f32x4 v = out[nt][j];
-            if (TRACK == 1 && live) track_range(v, imax, umax);
-            // mode 2: the pre-clamp values are finite here (finite weights times bounded layer-1 rows: no inf, no NaN) and only a
-            // POSITIVE excursion is clamped, so the largest value is all there is to watch -- a plain float maximum, two values per
-            // instruction (the first reader of these matrix-pipe results is the compiler-visible v_med3 below: the maxima sit behind it)
-            f32x4 w = v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = relu_sat16(v[e]);
-            if (TRACK == 2 && live) { max_after2(fmx, v[0], v[1], w[0], w[1]); max_after2(fmx, v[2], v[3], w[2], w[3]); }
-            if (live) store_split4(sm, plane_off(node, (col0 + 16 * j) >> 3) + ((2 * (col0 + 16 * j)) & 15), v);
-        }
+        for (int e = 0; e < 4; ++e) v[e] = relu_sat16(v[e]);
+        if (TRACK == 2 && live) { max_after2(fmx, v[0], v[1], w[0], w[1]); max_after2(fmx, v[2], v[3], w[2], w[3]); }
+        if (live) store_split4(sm, plane_off(node, col0 >> 3) + ((2 * col0) & 15), v);
     }
-    if (TRACK == 1) report_saturation(out_of_range(imax, umax), saturated);
     if (TRACK == 2) report_saturation(!(fmx <= 65504.0f), saturated);
 }
 
 __device__ __forceinline__ uint32_t bit_of64(uint64_t m, int s) {             // bit s of a wave-uniform 64-bit mask
     const uint32_t w = (s & 32) ? (uint32_t)(m >> 32) : (uint32_t)m;
     return (w >> (s & 31)) & 1u;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Heads of ONE board by the workgroup that has just pooled it (8-wave form, launches of at most FUSE_HEADS_MAX boards -- the
-// MCTS's): policy MLP 128 -> 64 -> A (+ Softmax), value MLP 128 -> 64 -> 1 (+ Tanh), pv_network_gnn.py:38-51,:62-63, in exact
-// f32 on the vector unit.  One board is a matrix-vector product: nothing for the matrix pipe, but 128 KB of weights from L2
-// per board -- affordable for a few hundred boards per launch (a separate launch of the 16-boards-per-workgroup MFMA heads
-// costs 6.4 us + a kernel boundary per simulation there), not for 65,536.  `scr` = 5 KB of LDS (the plane image is dead).
-//   phase 1  hidden unit u = tid & 127 over k quarter tid >> 7 (32 coalesced weight loads in flight per thread)
-//   phase 2  action a = tid & 255 over hidden half tid >> 8;  wave 7 also reduces the value head
-//   phase 3  softmax over the A logits: DPP maxima / sums per wave, combined through LDS
-// ---------------------------------------------------------------------------------------------
-constexpr int FUSE_HEADS_MAX = 1024;
-struct alignas(16) FusedHeadsScratch {
-    alignas(16) float g[HID];            // pooled features of the board
-    alignas(16) float part[4][HID];      // hidden-layer partial sums of the four k quarters
-    alignas(16) float hid[HID];          // hidden activations: 0..63 policy head, 64..127 value head
-    alignas(16) float lpart[2][APAD];    // logit partial sums of the two hidden halves
-    float red[2][8];                     // per-wave softmax maxima / sums
-};
-static_assert(sizeof(FusedHeadsScratch) <= PPLANE, "fused heads scratch lives in the (dead) hi plane");
-
-__device__ __forceinline__ float wave_max_all(float x) {       // maximum of the 64 lanes, in every lane
-    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false)));
-    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false)));
-    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false)));
-    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false)));
-    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false)));
-    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, false)));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
-}
-__device__ __forceinline__ float wave_sum_all(float x) {       // fixed-order sum of the 64 lanes, in every lane
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, false));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
-}
-
-// All 512 threads of the workgroup call this between two barriers of their own; on return the board's outputs are stored.
-__device__ __forceinline__ void fused_heads_512(FusedHeadsScratch& sc, __amdgpu_buffer_rsrc_t rs, const float* __restrict__ pk, int A, int tid,
-                                                float* __restrict__ logits_row, float* __restrict__ policy_row,
-                                                float* __restrict__ value_pre, float* __restrict__ value) {
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // (weights by buffer loads off the packed buffer's SGPR descriptor: lane offset + scalar row offset.  With plain pointers
-    //  the compiler precomputes all 64 row addresses per thread outside the board loop -- and spills them.)
-    {   // phase 1
-        const int u = tid & 127, kq = wave >> 1;
-        const int base = (int)(PackedLayout::HW1T * sizeof(float)) + (32 * kq) * (HID * 4);
-        float acc = 0.f;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {                 // two batches of 16 loads in flight
-            float wk[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) wk[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, u * 4, base + (16 * h + j) * (HID * 4), 0));
-#pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4) {
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(&sc.g[32 * kq + 16 * h + 4 * j4]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc = fmaf(gv[i], wk[4 * j4 + i], acc);
-            }
-        }
-        sc.part[kq][u] = acc;
-    }
-    __syncthreads();
-    if (tid < HID) sc.hid[tid] = fmaxf(((sc.part[0][tid] + sc.part[1][tid]) + (sc.part[2][tid] + sc.part[3][tid])) + pk[PackedLayout::HB1 + tid], 0.f);
-    __syncthreads();
-    {   // phase 2
-        const int a = tid & 255, uh = wave >> 2;
-        const int base = (int)(PackedLayout::PW2T * sizeof(float)) + (32 * uh) * (APAD * 4);
-        float acc = 0.f;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float wk[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) wk[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, a * 4, base + (16 * h + j) * (APAD * 4), 0));
-#pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4) {
-                const f32x4 hv = *reinterpret_cast<const f32x4*>(&sc.hid[32 * uh + 16 * h + 4 * j4]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc = fmaf(hv[i], wk[4 * j4 + i], acc);
-            }
-        }
-        sc.lpart[uh][a] = acc;
-        if (wave == 7) {     // value head: 64 hidden units, one per lane
-            const float v = wave_sum_all(sc.hid[HID / 2 + lane] * pk[PackedLayout::VW2 + lane]) + pk[PackedLayout::VB2];
-            if (lane == 0) {
-                if (value_pre) *value_pre = v;
-                if (value) *value = tanhf(v);
-            }
-        }
-    }
-    __syncthreads();
-    if (!logits_row && !policy_row) return;
-    // phase 3: waves 0..3 hold the logits (a = tid < 256), softmax over a < A
-    float lg = -INFINITY;
-    if (tid < APAD) {
-        if (tid < A) lg = (sc.lpart[0][tid] + sc.lpart[1][tid]) + pk[PackedLayout::PB2 + tid];
-        const float m = wave_max_all(lg);
-        if (lane == 0) sc.red[0][wave] = m;
-    }
-    __syncthreads();
-    float ex = 0.f, M = 0.f;
-    if (tid < APAD) {
-        M = fmaxf(fmaxf(sc.red[0][0], sc.red[0][1]), fmaxf(sc.red[0][2], sc.red[0][3]));
-        ex = tid < A ? expf(lg - M) : 0.f;
-        const float ssum = wave_sum_all(ex);
-        if (lane == 0) sc.red[1][wave] = ssum;
-    }
-    __syncthreads();
-    if (tid < A) {
-        const float S = (sc.red[1][0] + sc.red[1][1]) + (sc.red[1][2] + sc.red[1][3]);
-        if (logits_row) logits_row[tid] = lg;
-        if (policy_row) policy_row[tid] = ex / S;
-    }
 }
 
 // The lane index, re-derived from the execution mask (two v_mbcnt) wherever it is needed instead of being kept in a register across
@@ -1192,7 +971,7 @@ __device__ __forceinline__ Planes degree_planes(const Open& op) {
     }
     return p;
 }
-// build_inputs: everything a board's layers read from LDS besides the planes, into buffer `par` --
+// build_inputs: everything a board's layers read from LDS besides the planes --
 //  (1) layer-1 input, aggregated first (GCNConv is linear before its ReLU: A_hat (X W) = (A_hat X) W, and X has 6 columns where
 //      X W has 128):  G'[n][f] = sum_{k in N[n]} X0[k][f] / sqrt(deg k)  (the 1 / sqrt(deg n) half of the symmetric norm cancels
 //      against the sqrt(deg) scale of the plane image).  Wave f < 6 owns feature f for all 81 nodes (lane = node `lane`, lanes
@@ -1201,58 +980,47 @@ __device__ __forceinline__ Planes degree_planes(const Open& op) {
 //      v_cndmask; x / sqrt(deg) goes through 384 bytes of the wave's own LDS scratch to reach the four neighbours (no other
 //      wave is involved: no barrier), the sum is split into fp16 hi / lo and stored as the B operand rows of layer 1;
 //  (2) the banded adjacency fragments of layers 2 and 3.
-// Called for the first board of a workgroup before the loop, and for board b + 1 under board b's layer 3 (the buffers of the
-// other parity were last read a whole board ago: four barriers back).
-template <int NWV>
+// `what` & 1: the G' rows (top of a board), & 2: the adjacency fragments (behind layer 1).
 __device__ __forceinline__ void trunk_build_inputs(unsigned short (&G16)[81][16], unsigned int (&AF)[AF_BLOCKS][64][4], float* __restrict__ Yw,
-                                               unsigned short (&degv)[NWV == 4 ? 3 : 2][32], const float (&dtab)[8], int wave, uint64_t hw, uint64_t vw, uint32_t hd, int what) {
-constexpr int N = 9, V = 81, NSLOT = NWV == 4 ? 3 : 2;
+                                               unsigned short (&degv)[2][32], const float (&dtab)[8], int wave, uint64_t hw, uint64_t vw, uint32_t hd, int what) {
+    constexpr int N = 9, V = 81, NSLOT = 2;
     const Open op = make_open<N>(hw, vw);
     const Planes pl = degree_planes(op);
-#ifdef AQG_ABL_GP       // timing-only (tools/ab_trunk.py): no layer-1 input rows
-    what &= ~1;
-#endif
-#ifdef AQG_ABL_AFB      // timing-only: no adjacency fragments
-    what &= ~2;
-#endif
     if (what & 1) {
         const int ppos = hd & 0xff, pwl = (hd >> 8) & 0xff, epos = (hd >> 16) & 0xff, ewl = hd >> 24;
         const BB shb = spread_slots<N>(hw), svb = spread_slots<N>(vw);
-#pragma unroll
-        for (int it = 0; it < (6 + NWV - 1) / NWV; ++it) {
-            const int f = __builtin_amdgcn_readfirstlane(wave + NWV * it);   // wave-uniform, and known to be: the masks below stay scalar
-            if (f < 6) {
-                BB m = mask_all<N>();
-                float sc = 1.f;
-                if (f == 0) m = bb_bit(ppos);
-                else if (f == 1) sc = (float)pwl;
-                else if (f == 2) m = bb_bit(epos);
-                else if (f == 3) sc = (float)ewl;
-                else if (f == 4) m = shb;
-                else m = svb;
-                const int ln = fresh_lane(), l1 = min(ln, 16);
-                // 1 / sqrt(deg) of this lane's two nodes from the table: byte offset (deg - 1) * 4 assembled from the three degree bit planes
-                const float dnv0 = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(dtab) + (lane_val<4>(pl.b0l) | lane_val<8>(pl.b1l) | lane_val<16>(pl.b2l)));
-                const float dnv1 = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(dtab) + (lane_val<4>(pl.b0h) | lane_val<8>(pl.b1h) | lane_val<16>(pl.b2h)));
-                const float y0 = lane_sel(m.lo, sc) * dnv0, y1 = lane_sel(m.hi, sc) * dnv1;
-                                Yw[ln] = y0;
-                if (ln < 17) Yw[64 + ln] = y1;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // (an edge that is open leads to a node of the board: clamped addresses are only ever read by lanes that discard them)
-                const float nu0 = Yw[max(ln - 9, 0)], nd0 = Yw[ln + 9], nl0 = Yw[max(ln - 1, 0)], nr0 = Yw[ln + 1];
-                const float nu1 = Yw[55 + l1], nd1 = Yw[73 + l1], nl1 = Yw[63 + l1], nr1 = Yw[65 + l1];
-                const float g0 = (((y0 + lane_sel(op.U.lo, nu0)) + lane_sel(op.D.lo, nd0)) + lane_sel(op.L.lo, nl0)) + lane_sel(op.R.lo, nr0);
-                const float g1 = (((y1 + lane_sel(op.U.hi, nu1)) + lane_sel(op.D.hi, nd1)) + lane_sel(op.L.hi, nl1)) + lane_sel(op.R.hi, nr1);
-                const _Float16 h0 = (_Float16)g0, h1 = (_Float16)g1;
-                const _Float16 e0 = (_Float16)(g0 - (float)h0), e1 = (_Float16)(g1 - (float)h1);
-                G16[ln][f] = __builtin_bit_cast(unsigned short, h0);
-                G16[ln][8 + f] = __builtin_bit_cast(unsigned short, e0);
-                if (ln < 17) {
-                    G16[64 + ln][f] = __builtin_bit_cast(unsigned short, h1);
-                    G16[64 + ln][8 + f] = __builtin_bit_cast(unsigned short, e1);
-                }
+        const int f = __builtin_amdgcn_readfirstlane(wave);        // wave-uniform, and known to be: the masks below stay scalar
+        if (f < 6) {
+            BB m = mask_all<N>();
+            float sc = 1.f;
+            if (f == 0) m = bb_bit(ppos);
+            else if (f == 1) sc = (float)pwl;
+            else if (f == 2) m = bb_bit(epos);
+            else if (f == 3) sc = (float)ewl;
+            else if (f == 4) m = shb;
+            else m = svb;
+            const int ln = fresh_lane(), l1 = min(ln, 16);
+            // 1 / sqrt(deg) of this lane's two nodes from the table: byte offset (deg - 1) * 4 assembled from the three degree bit planes
+            const float dnv0 = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(dtab) + (lane_val<4>(pl.b0l) | lane_val<8>(pl.b1l) | lane_val<16>(pl.b2l)));
+            const float dnv1 = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(dtab) + (lane_val<4>(pl.b0h) | lane_val<8>(pl.b1h) | lane_val<16>(pl.b2h)));
+            const float y0 = lane_sel(m.lo, sc) * dnv0, y1 = lane_sel(m.hi, sc) * dnv1;
+                            Yw[ln] = y0;
+            if (ln < 17) Yw[64 + ln] = y1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // (an edge that is open leads to a node of the board: clamped addresses are only ever read by lanes that discard them)
+            const float nu0 = Yw[max(ln - 9, 0)], nd0 = Yw[ln + 9], nl0 = Yw[max(ln - 1, 0)], nr0 = Yw[ln + 1];
+            const float nu1 = Yw[55 + l1], nd1 = Yw[73 + l1], nl1 = Yw[63 + l1], nr1 = Yw[65 + l1];
+            const float g0 = (((y0 + lane_sel(op.U.lo, nu0)) + lane_sel(op.D.lo, nd0)) + lane_sel(op.L.lo, nl0)) + lane_sel(op.R.lo, nr0);
+            const float g1 = (((y1 + lane_sel(op.U.hi, nu1)) + lane_sel(op.D.hi, nd1)) + lane_sel(op.L.hi, nl1)) + lane_sel(op.R.hi, nr1);
+            const _Float16 h0 = (_Float16)g0, h1 = (_Float16)g1;
+            const _Float16 e0 = (_Float16)(g0 - (float)h0), e1 = (_Float16)(g1 - (float)h1);
+            G16[ln][f] = __builtin_bit_cast(unsigned short, h0);
+            G16[ln][8 + f] = __builtin_bit_cast(unsigned short, e0);
+            if (ln < 17) {
+                G16[64 + ln][f] = __builtin_bit_cast(unsigned short, h1);
+                G16[64 + ln][8 + f] = __builtin_bit_cast(unsigned short, e1);
             }
         }
     }
@@ -1268,10 +1036,9 @@ constexpr int N = 9, V = 81, NSLOT = NWV == 4 ? 3 : 2;
         auto open_word = [&](int dir, int w) -> uint32_t {
             return dir == 0 ? sel3(u0, u1, u2, w) : dir == 1 ? sel3(d0w, d1w, d2w, w) : dir == 2 ? sel3(l0, l1, l2, w) : sel3(r0w, r1w, r2w, w);
         };
-        // ten adjacency blocks over the waves:   8 waves: w0 {8}  w1 {9}  w2 {0,6}  w3 {1,7}  w4..7 {2..5}      4 waves: w0 {0,4}  w1 {1,5}  w2 {2,6,8}  w3 {3,7,9}
+        // ten adjacency blocks over the eight waves:   w0 {8}  w1 {9}  w2 {0,6}  w3 {1,7}  w4..7 {2..5}
         auto slot_block = [&](int it) -> int {                           // wave-uniform
-            if (NWV == 8) return it == 0 ? (wave >= 2 ? wave - 2 : wave + 8) : ((wave == 2 || wave == 3) ? wave + 4 : AF_BLOCKS);
-            return it < 2 ? wave + 4 * it : (wave >= 2 ? wave + 6 : AF_BLOCKS);
+            return it == 0 ? (wave >= 2 ? wave - 2 : wave + 8) : ((wave == 2 || wave == 3) ? wave + 4 : AF_BLOCKS);
         };
         // step 1: the fp16 values CQ / deg(k) of the 32 source nodes of each block's k range, through this wave's own LDS
         //         scratch (lane l < 32 = node 32 kb + l; the word of the open-edge boards is wave-uniform)
@@ -1316,7 +1083,7 @@ constexpr int N = 9, V = 81, NSLOT = NWV == 4 ? 3 : 2;
                         const uint32_t nib = (win4 >> (uint32_t)min(max(d0 + 16 * h, 0), 31)) & 0xFu;
                         const uint32_t t2 = nib | (nib << 15);           // b0 -> bit 0, b1 -> bit 16, b2 -> bit 2, b3 -> bit 18
                         // a packed 16-bit multiply by the 0 / 1 of each half keeps or clears the half (v_pk_mul_lo_u16)
-                        // (scalars first: __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index -- hipcc 7.2, see track_range)
+                        // (scalars first: __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index -- hipcc 7.2, see the range-guard comment)
                         typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
                         const uint32_t dv0 = dv[0], dv1 = dv[1], s0 = t2 & 0x00010001u, s1 = (t2 >> 2) & 0x00010001u;
                         fr[2 * h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, s0) * __builtin_bit_cast(u16x2, dv0));
@@ -1355,50 +1122,23 @@ __device__ __forceinline__ void trunk_bias_offsets(uint64_t hw, uint64_t vw, int
 // are checked instead, on the scalar unit.  2 (every other weight set) = the values are bounded where that is cheapest: layer 1's
 // pre-clamp outputs by a float maximum; the linear maps' outputs U (which are split themselves) by a float maximum of |U| against the
 // thresholds of PackedLayout::GUARD -- layer 2's aggregate is then below 65504 by  |V| <= 2.0625 max|U| + max|TB|,  layer 3's is not
-// split at all (the heads check the pooled row): one vector instruction per TWO values at three places instead of one per value at
-// five (mode 1, the bit-pattern tracking of every epilogue value, still used by the pair form).
-template <int JT, int WGS_PER_CU, bool FUSE = false, int TRACK = 2>
-#ifdef AQG_TRUNK96
-// Experiment build: the 8-wave form capped at 96 vector registers (the compiler only honours a waves-per-SIMD request beyond what
-// the kernel's LDS allows when it cannot see the LDS size, hence dynamic LDS here): four trunk waves then leave 128 registers of a
-// SIMD free and an MCTS step wave (112) fits beside them -- a step workgroup no longer displaces a trunk workgroup (section K4).
-#define AQG_TRUNK_BOUNDS __attribute__((amdgpu_flat_work_group_size(64 * (8 / JT), 64 * (8 / JT)), amdgpu_waves_per_eu(JT == 1 ? 5 : 2, JT == 1 ? 5 : 2)))
-#else
-#define AQG_TRUNK_BOUNDS __launch_bounds__(64 * (8 / JT), WGS_PER_CU * (2 / JT))
-#endif
-__global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restrict__ states, int fmt, int B,
-                                                                                        const float* __restrict__ pk,
-                                                                                        float* __restrict__ pooled,
-                                                                                        const uint8_t* __restrict__ active, int phase_delay,
-                                                                                        int A = 0, float* __restrict__ logits = nullptr,
-                                                                                        float* __restrict__ policy = nullptr,
-                                                                                        float* __restrict__ value_pre = nullptr,
-                                                                                        float* __restrict__ value = nullptr,
-                                                                                        int32_t* __restrict__ saturated = nullptr) {
-    static_assert(!FUSE || JT == 1, "the fused heads are written for the 512-thread form");
+// split at all (the heads check the pooled row): one vector instruction per TWO values at three places.
+template <int TRACK>
+__global__ __launch_bounds__(64 * NWV, 4) void gcn_trunk_boards_mm_kernel(const void* __restrict__ states, int fmt, int B, const float* __restrict__ pk,
+                                                                          float* __restrict__ pooled, const uint8_t* __restrict__ active,
+                                                                          int phase_delay, int32_t* __restrict__ saturated) {
     AQG_TRACE_BEGIN
-    constexpr int NWV = 8 / JT;
-#ifdef AQG_TRUNK96
-    extern __shared__ __align__(16) unsigned char aqg_dyn_smem[];
-    TrunkSmemM<NWV>& sm = *reinterpret_cast<TrunkSmemM<NWV>*>(aqg_dyn_smem);
-#else
-    __shared__ TrunkSmemM<NWV> sm;
-#endif
+    __shared__ TrunkSmemM sm;
     // The two workgroups resident on a CU run identical phase sequences; a start offset for the second-resident ones
     // (phase_delay x 64 cycles) keeps one on the matrix pipe while the other does vector work.
-#ifdef AQG_TRUNK_DELAY      // timing-only probe, as AQG_HEADS_DELAY: every trunk workgroup AQG_TRUNK_DELAY x ~1 us longer
-    for (int i = 0; i < AQG_TRUNK_DELAY; ++i) __builtin_amdgcn_s_sleep(36);
-#endif
     const int prio_mode = phase_delay >> 16;     // static wave priorities (aqg_set_option("trunk_prio"); chosen by launch size on the host)
     phase_delay &= 0xFFFF;
     for (int i = 0; i < (int)(blockIdx.x >> 8) * phase_delay; ++i) __builtin_amdgcn_s_sleep(1);   // 2nd / 3rd resident: 1x / 2x
-#ifndef AQG_NO_PRIO
     {
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const bool up = ((prio_mode & 1) && wv >= 4) || ((prio_mode & 2) && blockIdx.x >= 256) || ((prio_mode & 4) && blockIdx.x < 256);
         if (up) __builtin_amdgcn_s_setprio(1);
     }
-#endif
     // trunk_prio bit 3: the two workgroups of a CU take turns at priority 1, phase by phase, instead of the older one winning
     // every arbitration (otherwise the younger one's chain is 25 % longer)
     const int prio_sel = (prio_mode & 8) ? (int)((blockIdx.x >> 8) & 1) : -1;
@@ -1439,66 +1179,53 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
     // their first reader sits behind the first board's setup barrier.
     {
         const int t0 = (int)threadIdx.x;
-        for (int i = t0; i < (1 + AQG_PREFETCH) * 81 * 2; i += 64 * NWV)
-            *reinterpret_cast<unsigned int*>(&sm.G16[0][0][0] + 16 * (i >> 1) + 6 + 8 * (i & 1)) = 0u;
+        for (int i = t0; i < 81 * 2; i += 64 * NWV)
+            *reinterpret_cast<unsigned int*>(&sm.G16[0][0] + 16 * (i >> 1) + 6 + 8 * (i & 1)) = 0u;
         if (t0 < 8) sm.dinvtab[t0] = dinv_of_dm((uint32_t)t0) * (float)(1.0 / (81.0 * CQ));      // (first read behind the layer-3 barriers)
         if ((t0 & 63) < 8) sm.dinv1[t0 >> 6][t0 & 63] = dinv_of_dm((uint32_t)(t0 & 63));           // each wave its own copy: no barrier here
     }
-    u32x4 Bf[2][JT][4];
+    u32x4 Bf[2][4];
     const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pooled, 0, B * (HID * 4), 0x00020000);
 
-    auto decode = [&](uint32_t r0, uint32_t r1, uint64_t& hw, uint64_t& vw, uint32_t& hd) { trunk_decode(fmt, r0, r1, hw, vw, hd); };
-    auto build_inputs = [&](int par, uint64_t hw, uint64_t vw, uint32_t hd, int what) {
-        trunk_build_inputs<NWV>(sm.G16[par], sm.AF[par], sm.Y[wave], sm.degv[wave], sm.dinv1[wave], wave, hw, vw, hd, what);
+    auto build_inputs = [&](uint64_t hw, uint64_t vw, uint32_t hd, int what) {
+        trunk_build_inputs(sm.G16, sm.AF, sm.Y[wave], sm.degv[wave], sm.dinv1[wave], wave, hw, vw, hd, what);
     };
 
     AQG_STAMP_DECL
-    int par = 0;
-    bool first = true;
     while (b < B) {
         AQG_STAMP_AT(7)
         wave = wave0;
         asm volatile("" : "+s"(wave));         // opaque per board: wave-derived predicates are recomputed (2-3 scalar ops), not
                                                // hoisted out of the loop into registers that then spill
-        asm volatile("" : "+s"(par));
         const int lane = fresh_lane(), c = lane & 15, q = lane >> 4;
         // the small layer-1 weight fragment goes out first
-        u32x4 w1f[JT];
-#pragma unroll
-        for (int j = 0; j < JT; ++j) w1f[j] = load_frag16(rs, lane * 16, (int)(PackedLayout::WH1 * sizeof(float)) + (wave * JT + j) * (64 * 16));
+        const u32x4 w1f = load_frag16(rs, lane * 16, (int)(PackedLayout::WH1 * sizeof(float)) + wave * (64 * 16));
         __builtin_amdgcn_sched_barrier(0);
         int toff[3];
         uint64_t hw, vw;
         uint32_t hd;
-        decode(rec0, rec1, hw, vw, hd);
+        trunk_decode(fmt, rec0, rec1, hw, vw, hd);
         trunk_bias_offsets(hw, vw, c, q, toff);
-        f32x4 out[6][JT];
-        u32x4 zh[JT][3], zl[JT][3];
-        request_bias<JT>(out, rs, 0, toff, wave);                            // lands under the input build + barrier
+        f32x4 out[6];
+        u32x4 zh[3], zl[3];
+        request_bias(out, rs, 0, toff, wave);                            // lands under the input build + barrier
         AQG_STAMP_AT(6)
-#if defined(AQG_ABL_SETUP0)       // timing-only: no input build at all (what a workgroup would do if a board's fragments came ready-made)
-#elif defined(AQG_ABL_SETUP)
-        if (first) build_inputs(par, hw, vw, hd, 3);
-#else
-        if (!AQG_PREFETCH || first) build_inputs(par, hw, vw, hd, AQG_AF_AT == 0 ? 3 : 1);
-#endif
+        build_inputs(hw, vw, hd, 1);                                     // the layer-1 input rows G'
         int bn = b + gridDim.x;
         while (bn < B && active && !active[bn]) bn += gridDim.x;
-        AQG_BOARD_BARRIER();                     // this board's G' rows and adjacency fragments are complete; the previous board is done
+        AQG_BOARD_BARRIER();                     // this board's G' rows are complete; the previous board is done
         AQG_STAMP_AT(0)
         phase_prio(1);
         // ---- layer 1: one MFMA per node tile on top of the bias rows, relu, planes
         if (TRACK == 0 && (((hd >> 8) & 0xffu) > AQG_GNN_PROVEN_MAX_WALLS || (hd >> 24) > AQG_GNN_PROVEN_MAX_WALLS)) report_saturation(true, saturated);
-        layer1_store<JT, TRACK>(sm, sm.G16[par], w1f, out, wave, lane, saturated);
+        layer1_store<TRACK>(sm, sm.G16, w1f, out, wave, lane, saturated);
         AQG_STAMP_AT(8)
         __builtin_amdgcn_sched_barrier(0);
-        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights: land under the barrier
+        load_bfrag_mm(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights: land under the barrier
         __builtin_amdgcn_sched_barrier(0);
         phase_prio(2);
-#if !defined(AQG_ABL_SETUP) && !defined(AQG_ABL_SETUP0)
-        if (AQG_AF_AT == 1) build_inputs(par, hw, vw, hd, 2);
-#endif
+        build_inputs(hw, vw, hd, 2);                                     // the adjacency fragments of layers 2 and 3
         AQG_STAMP_AT(9)
         AQG_BOARD_BARRIER();
         AQG_STAMP_AT(1)
@@ -1506,16 +1233,13 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
         phase_prio(3);
         {
             float zmax = 0.f;
-            linear_split<JT>(sm, Bf, lane, zh, zl, [&]() { request_bias<JT>(out, rs, 1, toff, wave); }, TRACK == 2 ? &zmax : nullptr);
+            linear_split(sm, Bf, lane, zh, zl, [&]() { request_bias(out, rs, 1, toff, wave); }, TRACK == 2 ? &zmax : nullptr);
             if (TRACK == 2) report_saturation(!(zmax <= pk[PackedLayout::GUARD + 0]), saturated);
         }
         AQG_STAMP_AT(2)
-        // the adjacency fragments, here: the layer-2 weight fragments are dead (32 registers free), the layer-3 ones not yet
-        // requested, and the waves that finish the linear map first wait at the next barrier anyway
-        if (AQG_AF_AT == 2) build_inputs(par, hw, vw, hd, 2);
         AQG_STAMP_AT(11)
         __builtin_amdgcn_sched_barrier(0);
-        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH3, wave, lane);             // lands under the barrier + aggregation
+        load_bfrag_mm(Bf, rs, PackedLayout::WH3, wave, lane);             // lands under the barrier + aggregation
         uint32_t nrec0 = 0, nrec1 = 0;
         if (bn < B) fetch_record(bn, nrec0, nrec1);                         // the next board's record rides behind it
         __builtin_amdgcn_sched_barrier(0);
@@ -1523,45 +1247,23 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
         AQG_BOARD_BARRIER();                                                    // every wave is done reading the planes
         AQG_STAMP_AT(13)
         phase_prio(4);
-        aggregate_store<JT, false, TRACK>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, 0, saturated);
+        aggregate_store<false>(sm, sm.AF, zh, zl, out, wave, lane, toff, prs, 0);
         AQG_STAMP_AT(14)
         AQG_BOARD_BARRIER();
         AQG_STAMP_AT(3)
         // ---- layer 3 + mean pool
         phase_prio(5);
-        if (AQG_PREFETCH && bn < B) {
-            // the NEXT board's G' rows and adjacency fragments, into the other buffers: vector / scalar / LDS work that the two
-            // resident workgroups' matrix phases cover, instead of a setup phase in front of every board
-            uint64_t hw, vw;
-            uint32_t hd;
-            decode(nrec0, nrec1, hw, vw, hd);
-            build_inputs(par ^ 1, hw, vw, hd, AQG_AF_AT == 0 ? 3 : 1);
-        }
         AQG_STAMP_AT(10)
         {
             float zmax = 0.f;
-            linear_split<JT>(sm, Bf, lane, zh, zl, [&]() { request_bias<JT>(out, rs, 2, toff, wave); }, TRACK == 2 ? &zmax : nullptr);
+            linear_split(sm, Bf, lane, zh, zl, [&]() { request_bias(out, rs, 2, toff, wave); }, TRACK == 2 ? &zmax : nullptr);
             if (TRACK == 2) report_saturation(!(zmax <= pk[PackedLayout::GUARD + 1]), saturated);
         }
         AQG_STAMP_AT(4)
         AQG_STAMP_AT(15)
-        if constexpr (FUSE) {
-            // the board's heads, right here: the plane image is dead once every wave is past its layer-3 linear map (the barrier)
-            FusedHeadsScratch& hs = *reinterpret_cast<FusedHeadsScratch*>(&sm.P[0][0]);
-            AQG_BOARD_BARRIER();
-            aggregate_store<JT, true, TRACK>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, b * (HID * 4), saturated, hs.g);
-            AQG_BOARD_BARRIER();
-            const int tid = 64 * wave + lane;
-            fused_heads_512(hs, rs, pk, A, tid, logits ? logits + (size_t)b * A : nullptr, policy ? policy + (size_t)b * A : nullptr,
-                            value_pre ? value_pre + b : nullptr, value ? value + b : nullptr);
-        } else {
-            phase_prio(6);
-            aggregate_store<JT, true, TRACK>(sm, sm.AF[par], zh, zl, out, wave, lane, toff, prs, b * (HID * 4), saturated);
-        }
+        phase_prio(6);
+        aggregate_store<true>(sm, sm.AF, zh, zl, out, wave, lane, toff, prs, b * (HID * 4));
         rec0 = nrec0; rec1 = nrec1;
-        if (AQG_PREFETCH) par ^= 1;
-        else if (AQG_AF_AT == 0 && bn < B) AQG_BOARD_BARRIER();     // (fragments built in front of the top barrier: layer 3 still reads them)
-        first = false;
         // (No barrier at the end of a board: what the next board writes in front of its top barrier -- the G' rows, wave-private
         //  scratch -- was last read in layer 1 of this board, three barriers back; its planes and adjacency fragments are written
         //  behind that barrier, which no wave passes before every wave has finished this board's layer 3.)
@@ -1582,139 +1284,6 @@ __global__ AQG_TRUNK_BOUNDS void gcn_trunk_boards_mm_kernel(const void* __restri
 }
 
 
-// =============================================================================================
-// Pair form of the all-MFMA trunk (trunk_variant 7): ONE 8-wave workgroup per CU walks PAIRS of boards, every phase of the
-// algorithm above running for both boards of the pair before the next barrier.
-//   * the weight fragments of a layer (64 KB per workgroup from L2) are fetched once per PAIR, the barriers are paid once per
-//     pair (four per pair instead of four per board), and a wave has two boards' independent work between two barriers;
-//   * one workgroup of <= 256-register waves per CU: two waves per SIMD.
-// Timing-only ablations of the one-board form (tools/ab_trunk.py) put its matrix instructions at 20 % of its time, its barriers
-// at 16 %, everything else (weight / bias fragment traffic, splits, epilogues, setup) above 50 %: this form halves the first
-// two fixed costs per board.  Same arithmetic per board, same results.
-// LDS: 2 x (planes 41.5 KB + adjacency fragments 10 KB + G' rows 2.6 KB) + scratch = 113 KB.
-// =============================================================================================
-struct alignas(16) PairBoardSmem {
-    alignas(16) unsigned char P[2][PPLANE];            // fp16 hi / lo planes of this board's activation image
-    alignas(16) unsigned int AF[AF_BLOCKS][64][4];     // its adjacency fragments
-    alignas(16) unsigned short G16[81][16];            // its layer-1 input rows
-    alignas(16) float dinvtab[8];                      // as in TrunkSmemM
-    alignas(16) float dinv1[8];
-};
-struct alignas(16) TrunkPairSmem {
-    PairBoardSmem bd[2];
-    alignas(16) float Y[8][96];
-    alignas(16) unsigned short degv[8][2][32];
-};
-static_assert(sizeof(TrunkPairSmem) <= 160 * 1024, "one pair workgroup per CU");
-
-__global__ __launch_bounds__(512, 2) void gcn_trunk_pairs_kernel(const void* __restrict__ states, int fmt, int B, const float* __restrict__ pk,
-                                                                 float* __restrict__ pooled, const uint8_t* __restrict__ active,
-                                                                 int32_t* __restrict__ saturated) {
-    AQG_TRACE_BEGIN
-    constexpr int JT = 1, NWV = 8;
-    __shared__ TrunkPairSmem sm;
-    const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int wave = wave0;
-    const int npairs = (B + 1) >> 1;
-    int p = blockIdx.x;
-    const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(states), 0, B * (fmt == 0 ? 72 : 24), 0x00020000);
-    auto fetch_record = [&](int bb, uint32_t& r0, uint32_t& r1) {
-        const int ln = fresh_lane();
-        if (fmt == 0) {
-            r0 = __builtin_amdgcn_raw_buffer_load_b8(rst, 4 + ln, bb * 72, 0);
-            r1 = __builtin_amdgcn_raw_buffer_load_b32(rst, 0, bb * 72, 0);
-        } else {
-            r0 = __builtin_amdgcn_raw_buffer_load_b32(rst, (ln < 5 ? ln : 4) * 4, bb * 24, 0);
-        }
-    };
-    // a board of a pair is live when it exists and is not masked out (workgroup-uniform); a pair with no live board is skipped
-    auto live_of = [&](int b) -> bool { return b < B && !(active && !active[b]); };
-    auto next_pair = [&](int q0) -> int { while (q0 < npairs && !live_of(2 * q0) && !live_of(2 * q0 + 1)) q0 += gridDim.x; return q0; };
-    uint32_t rec0[2] = {0u, 0u}, rec1[2] = {0u, 0u};
-    // the first pair's records are requested before its `active` flags are known (two loads in flight together)
-    if (p < npairs) {
-        fetch_record(min(2 * p, B - 1), rec0[0], rec1[0]);
-        fetch_record(min(2 * p + 1, B - 1), rec0[1], rec1[1]);
-        const int p1 = next_pair(p);
-        if (p1 != p) {
-            p = p1;
-            if (p < npairs) { fetch_record(min(2 * p, B - 1), rec0[0], rec1[0]); fetch_record(min(2 * p + 1, B - 1), rec0[1], rec1[1]); }
-        }
-    }
-    // once per workgroup: the k-slots 6, 7 of the hi and lo halves of every G' row, which no board ever writes
-    for (int i = (int)threadIdx.x; i < 2 * 81 * 2; i += 512)
-        *reinterpret_cast<unsigned int*>(&sm.bd[i / 162].G16[0][0] + 16 * ((i % 162) >> 1) + 6 + 8 * (i & 1)) = 0u;
-    if (threadIdx.x < 16) {
-        sm.bd[threadIdx.x >> 3].dinvtab[threadIdx.x & 7] = dinv_of_dm((uint32_t)(threadIdx.x & 7)) * (float)(1.0 / (81.0 * CQ));
-        sm.bd[threadIdx.x >> 3].dinv1[threadIdx.x & 7] = dinv_of_dm((uint32_t)(threadIdx.x & 7));
-    }
-    __syncthreads();
-    u32x4 Bf[2][JT][4];
-    const __amdgpu_buffer_rsrc_t rs = packed_rsrc(pk);
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pooled, 0, B * (HID * 4), 0x00020000);
-
-    while (p < npairs) {
-        wave = wave0;
-        asm volatile("" : "+s"(wave));
-        const int lane = fresh_lane(), c = lane & 15, q = lane >> 4;
-        const bool live0 = live_of(2 * p), live1 = live_of(2 * p + 1);      // workgroup-uniform
-        u32x4 w1f[JT];
-#pragma unroll
-        for (int j = 0; j < JT; ++j) w1f[j] = load_frag16(rs, lane * 16, (int)(PackedLayout::WH1 * sizeof(float)) + (wave * JT + j) * (64 * 16));
-        __builtin_amdgcn_sched_barrier(0);
-        int toff[2][3];
-        uint64_t hw[2], vw[2];
-        uint32_t hd[2];
-        f32x4 out[2][6][JT];
-        u32x4 zh[2][JT][3], zl[2][JT][3];
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            trunk_decode(fmt, rec0[d], rec1[d], hw[d], vw[d], hd[d]);
-            trunk_bias_offsets(hw[d], vw[d], c, q, toff[d]);
-            request_bias<JT>(out[d], rs, 0, toff[d], wave);                // lands under the input build + barrier
-        }
-        if (live0) trunk_build_inputs<NWV>(sm.bd[0].G16, sm.bd[0].AF, sm.Y[wave], sm.degv[wave], sm.bd[0].dinv1, wave, hw[0], vw[0], hd[0], 1);
-        if (live1) trunk_build_inputs<NWV>(sm.bd[1].G16, sm.bd[1].AF, sm.Y[wave], sm.degv[wave], sm.bd[1].dinv1, wave, hw[1], vw[1], hd[1], 1);
-        const int pn = next_pair(p + gridDim.x);
-        __syncthreads();                      // both boards' G' rows are complete; the previous pair is done
-        // ---- layer 1
-        if (live0) layer1_store<JT, 1>(sm.bd[0], sm.bd[0].G16, w1f, out[0], wave, lane, saturated);
-        if (live1) layer1_store<JT, 1>(sm.bd[1], sm.bd[1].G16, w1f, out[1], wave, lane, saturated);
-        __builtin_amdgcn_sched_barrier(0);
-        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH2, wave, lane);             // layer-2 weights, once for the pair
-        __builtin_amdgcn_sched_barrier(0);
-        if (live0) trunk_build_inputs<NWV>(sm.bd[0].G16, sm.bd[0].AF, sm.Y[wave], sm.degv[wave], sm.bd[0].dinv1, wave, hw[0], vw[0], hd[0], 2);
-        if (live1) trunk_build_inputs<NWV>(sm.bd[1].G16, sm.bd[1].AF, sm.Y[wave], sm.degv[wave], sm.bd[1].dinv1, wave, hw[1], vw[1], hd[1], 2);
-        __syncthreads();
-        // ---- layer 2
-        if (live0) request_bias<JT>(out[0], rs, 1, toff[0], wave);
-        if (live1) request_bias<JT>(out[1], rs, 1, toff[1], wave);
-        if (live0) linear_split<JT>(sm.bd[0], Bf, lane, zh[0], zl[0]);
-        if (live1) linear_split<JT>(sm.bd[1], Bf, lane, zh[1], zl[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        load_bfrag_mm<JT>(Bf, rs, PackedLayout::WH3, wave, lane);             // lands under the barrier + aggregation
-        uint32_t nrec0[2] = {0u, 0u}, nrec1[2] = {0u, 0u};
-        if (pn < npairs) { fetch_record(min(2 * pn, B - 1), nrec0[0], nrec1[0]); fetch_record(min(2 * pn + 1, B - 1), nrec0[1], nrec1[1]); }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                                                    // every wave is done reading the planes
-        if (live0) aggregate_store<JT, false, 1>(sm.bd[0], sm.bd[0].AF, zh[0], zl[0], out[0], wave, lane, toff[0], prs, 0, saturated);
-        if (live1) aggregate_store<JT, false, 1>(sm.bd[1], sm.bd[1].AF, zh[1], zl[1], out[1], wave, lane, toff[1], prs, 0, saturated);
-        __syncthreads();
-        // ---- layer 3 + mean pool
-        if (live0) request_bias<JT>(out[0], rs, 2, toff[0], wave);
-        if (live1) request_bias<JT>(out[1], rs, 2, toff[1], wave);
-        if (live0) linear_split<JT>(sm.bd[0], Bf, lane, zh[0], zl[0]);
-        if (live1) linear_split<JT>(sm.bd[1], Bf, lane, zh[1], zl[1]);
-        if (live0) aggregate_store<JT, true, 1>(sm.bd[0], sm.bd[0].AF, zh[0], zl[0], out[0], wave, lane, toff[0], prs, (2 * p) * (HID * 4), saturated);
-        if (live1) aggregate_store<JT, true, 1>(sm.bd[1], sm.bd[1].AF, zh[1], zl[1], out[1], wave, lane, toff[1], prs, (2 * p + 1) * (HID * 4), saturated);
-        rec0[0] = nrec0[0]; rec0[1] = nrec0[1]; rec1[0] = nrec1[0]; rec1[1] = nrec1[1];
-        // (no barrier at the end of a pair: see the one-board form)
-        p = pn;
-    }
-    AQG_TRACE_END(2, (unsigned long long)(uintptr_t)pooled)
-}
-
-// ---------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------
 // heads: 16 boards per workgroup
 // ---------------------------------------------------------------------------------------------
@@ -1873,10 +1442,6 @@ __global__ __launch_bounds__(256, 2) void gcn_heads_mm_kernel(const float* __res
     // a short latency chain that shares its CUs with other game sets' trunk workgroups: at a higher wave priority it is out of their
     // way sooner, and a microsecond of it is worth 0.5-0.6 us of every round of the self-play loop (option "heads_prio", 0..3)
     if (prio == 1) __builtin_amdgcn_s_setprio(1); else if (prio == 2) __builtin_amdgcn_s_setprio(2); else if (prio == 3) __builtin_amdgcn_s_setprio(3);
-#ifdef AQG_HEADS_DELAY      // timing-only probe (tools/ab_trunk.py --bench): the heads launch made AQG_HEADS_DELAY x ~1 us longer, to read
-                            // off how much of a set's step -> trunk -> heads chain ends up in the generation time
-    for (int i = 0; i < AQG_HEADS_DELAY; ++i) __builtin_amdgcn_s_sleep(36);
-#endif
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * 16;
@@ -2045,12 +1610,9 @@ AQG_TRACE_SETTER(set_trace_gcn)
 
 // Trunk variants (aqg_set_option("trunk_variant", v)):
 //   0 exact f32-input MFMA + VALU gather, weights resident, 1 workgroup/CU      1 the same, 2 workgroups/CU
-//   3 all-MFMA fp16 split trunk [default] = 6: 8 waves per board x 2 workgroups/CU
-//   5 (and 4, kept as an alias of the retired three-workgroups-per-CU form) 4 waves per board x 2 workgroups/CU
-// An earlier split-precision kernel kept the VALU gather of variants 0/1 on a 16-bit plane image (bf16 x6 / x3 and
-// fp16 x3 forms).  It was removed: its gather read plane bytes no wave had written for the current board (harmless
-// with benign leftovers, wrong once the LDS held NaN patterns -- tools/cold_launch_check.py poisons the LDS before
-// the first launch of a process to catch exactly this class of bug).
+//   3 all-MFMA fp16 split trunk [default] (6 = the same): 8 waves per board x 2 workgroups/CU
+// (Retired: a split kernel with the VALU gather on 16-bit planes -- it read plane bytes no wave had written, see DESIGN.md section 3 --,
+//  the 4-wave x 2 form, the pair form and the per-board VALU heads inside the trunk: all measured slower, all in the history.)
 int g_trunk_variant = 3;
 int g_heads_prio = 3;             // wave priority of the heads kernel (option "heads_prio", 0..3): round 3, same-box runs: 0 -> 1,626 / 1,641 games/s,
                                   // 1 -> 1,644 / 1,648, 2 -> 1,646, 3 -> 1,657 (profiles/r03_trunk_ab_runs.log)
@@ -2063,10 +1625,6 @@ int g_trunk_phase_delay = 100;   // x 64 cycles: start offset of the second-resi
 int g_trunk_delay_min_boards = 2048;   // launches below this many boards start all workgroups together (tools/phase_scan.py:
                                        // +4 % at 2,048 boards, +8 % at 4,096, +15-19 % from 8,192 on the three-per-CU form)
 int g_trunk_grid = 0;      // 0 = default persistent grid; otherwise override (diagnostics)
-int g_fuse_heads = 0;      // 1: launches of <= FUSE_HEADS_MAX boards compute their boards' heads inside the trunk workgroups.  OFF by
-                           // default: measured 6.8 us per board on top of the trunk's 14.2 (a matrix-vector product per workgroup is five
-                           // barrier-separated L2 round trips) against 6.4 us for the separate 16-boards-per-workgroup MFMA launch that
-                           // other game sets' kernels can overlap; self-play fell from 1,516 to 1,157 games/s with it on
 
 // Diagnostic: fill every CU's LDS with NaN bit patterns so that any read-before-write in a later kernel shows up
 // deterministically (used by the parity tests; LDS contents are otherwise whatever the previous kernel left).
@@ -2124,11 +1682,6 @@ int profile_collect(double* total_ms, long long* launches, long long* boards, in
     return 0;
 }
 
-#ifdef AQG_TRUNK96
-#define AQG_TRUNK_DYN(nwv) sizeof(TrunkSmemM<nwv>)
-#else
-#define AQG_TRUNK_DYN(nwv) 0
-#endif
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
                               int flags, int32_t* saturated, hipStream_t st) {
@@ -2139,7 +1692,6 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     const int A = N * N + 2 * (N - 1) * (N - 1);
     // persistent grid: 256 CUs x resident workgroups per CU, grid-stride over boards
     const int variant = (flags & 1) ? (g_trunk_variant == 0 ? 0 : 1) : g_trunk_variant;   // AQG_GNN_EXACT_F32
-    bool fused = false;
     if (g_profile_trunk == 1) { (void)hipEventRecord(prof_event(), st); g_prof_boards += B; }
     if (variant == 0) {
         int grid = B < 256 ? B : 256;
@@ -2147,38 +1699,19 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     } else if (variant == 1) {
         int grid = B < 512 ? B : 512;
         hipLaunchKernelGGL((gcn_trunk_boards_kernel<false, 2>), dim3(grid), dim3(256), 0, st, states, fmt, B, packed, pooled, active);
-    } else if (variant == 7) {
-        // pair form: one workgroup per CU, two boards per pass
-        int grid = (B + 1) / 2 < 256 ? (B + 1) / 2 : 256;
-        if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL(gcn_trunk_pairs_kernel, dim3(grid), dim3(512), 0, st, states, fmt, B, packed, pooled, active, saturated);
-    } else if (variant == 4 || variant == 5) {
-        // two 4-wave workgroups per CU (a wave owns 32 feature columns): half the LDS operand traffic of the 8-wave form
-        int grid = B < 512 ? B : 512;
-        if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, 2>), dim3(grid), dim3(256), AQG_TRUNK_DYN(4), st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),
-                           0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, saturated);
     } else {
         // two 8-wave workgroups per CU (a wave owns 16 feature columns): shortest latency per board AND, with four waves per
         // SIMD to hide each other's vector work, the highest throughput at every launch size (tools/trunk_scan.py)
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        const bool want_heads = logits || policy || value_pre || value;
-        if (want_heads && g_fuse_heads && B <= FUSE_HEADS_MAX && N * N + 2 * (N - 1) * (N - 1) <= APAD) {
-            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2, true>), dim3(grid), dim3(512), AQG_TRUNK_DYN(8), st, states, fmt, B, packed, pooled, active, 0,
-                               N * N + 2 * (N - 1) * (N - 1), logits, policy, value_pre, value, saturated);
-            fused = true;
-        } else if ((flags & AQG_GNN_RANGE_PROVEN) && saturated) {
-            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2, false, 0>), dim3(grid), dim3(512), AQG_TRUNK_DYN(8), st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),
-                               0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, saturated);
-        } else {
-            hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<1, 2>), dim3(grid), dim3(512), AQG_TRUNK_DYN(8), st, states, fmt, B, packed, pooled, active, (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16),
-                               0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, saturated);
-        }
+        const int opts = (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16);
+        if ((flags & AQG_GNN_RANGE_PROVEN) && saturated)
+            hipLaunchKernelGGL(gcn_trunk_boards_mm_kernel<0>, dim3(grid), dim3(64 * NWV), 0, st, states, fmt, B, packed, pooled, active, opts, saturated);
+        else
+            hipLaunchKernelGGL(gcn_trunk_boards_mm_kernel<2>, dim3(grid), dim3(64 * NWV), 0, st, states, fmt, B, packed, pooled, active, opts, saturated);
     }
     if (g_profile_trunk == 1) (void)hipEventRecord(prof_event(), st);
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;
-    if (fused) return 0;                                        // the trunk workgroups did their boards' heads themselves
     if (!logits && !policy && !value_pre && !value) return 0;   // trunk only (bench: time the dominant kernel alone)
     if (variant >= 3 && A <= 14 * 16) {
         hipLaunchKernelGGL(gcn_heads_mm_kernel, dim3((B + 15) / 16), dim3(256), 0, st, (const float*)pooled, B, A, packed,

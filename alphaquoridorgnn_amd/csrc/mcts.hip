@@ -35,7 +35,7 @@ size_t boards_any_workspace_floats(int N, int B);
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
                                   float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st);
-extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, g_profile_trunk, g_fuse_heads, g_trunk_prio, g_heads_prio;
+extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, g_profile_trunk, g_trunk_prio, g_heads_prio;
 void profile_mark(hipStream_t st, long long units);
 int g_use_graph = 1;       // aqg_set_option("use_graph", 0) forces plain launches
 
@@ -1004,7 +1004,7 @@ template <int N>
 static int run_sims(const aqg_engine& e, hipStream_t st) {
     if (!g_use_graph || g_profile_trunk || st == nullptr || e.sims < 4) return enqueue_sims<N>(e, st);
     // every option a captured launch bakes in is part of the key: a changed option must never replay a stale graph
-    const int opts[8] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth, g_fuse_heads | ((g_trunk_prio & 0xff) << 8) | (g_step_waves << 16) | (g_step_prio << 24) | (g_heads_prio << 28)};
+    const int opts[8] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth, ((g_trunk_prio & 0xff) << 8) | (g_step_waves << 16) | (g_step_prio << 24) | (g_heads_prio << 28)};
     for (SimGraph& g : g_sim_graphs)
         if (!memcmp(&g.e, &e, sizeof(aqg_engine)) && !memcmp(g.opts, opts, sizeof(opts))) return replay(g, st);
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {

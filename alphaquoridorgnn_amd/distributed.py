@@ -13,8 +13,15 @@ parked inside a collective: with RCCL a pending barrier is bounded by the proces
 two hours here instead of torch's ten minutes) and would abort the job once a stage outgrows it (25,000-game generations, the
 reference's original constants).  `wait_for_rank0(tag)` therefore parks the idle ranks on a key of the rendezvous store -- a
 host-side wait with no collective in flight -- until rank 0 publishes it with `release_ranks(tag)`; only then do all ranks meet
-in the (now immediate) barrier.
+in the (now immediate) barrier.  A stage that FAILS publishes the key too (value b"fail", `single_rank_stage`): the idle ranks wake
+up and raise within seconds, and `shutdown(ok=False)` tears the group down without a barrier, so the job ends with rank 0's own
+exception instead of a barrier timeout hours later.
+
+AQG_DIST_FORCE_GROUP=1 creates the process group even for a single rank (WORLD_SIZE absent or 1) and makes `engine.gather_history`
+run its collectives at world size 1: the RCCL communicator, its streams and the all-gather code path execute on ONE GPU
+(tests/test_gpu_parity.py::test_rccl_world_size_1_self_play_equals_no_group, bench.py leg `rccl_group_alive`).
 """
+import contextlib
 import datetime
 import os
 
@@ -51,8 +58,14 @@ def init_from_env(backend=None):
     n_gpu = torch.cuda.device_count()                       # does not initialise the runtime
     if n_gpu > 0:
         torch.cuda.set_device(local % n_gpu)                # before ANY other GPU call; ranks beyond the GPU count share (rehearsals)
-    if world <= 1 or (dist.is_available() and dist.is_initialized()):
+    if dist.is_available() and dist.is_initialized():
         return rank_world()
+    if world <= 1:
+        if not force_group():
+            return rank_world()
+        os.environ.setdefault("RANK", "0")                  # a one-rank group on this GPU (see the module docstring)
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
     backend = backend or os.environ.get("AQG_DIST_BACKEND", "nccl")
     timeout = datetime.timedelta(seconds=int(os.environ.get("AQG_DIST_TIMEOUT_S", "7200")))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -66,11 +79,35 @@ def init_from_env(backend=None):
     return dist.get_rank(), dist.get_world_size()
 
 
-def shutdown():
+def force_group():
+    """AQG_DIST_FORCE_GROUP=1: the group exists and the exchange step's collectives run even with one rank."""
+    return os.environ.get("AQG_DIST_FORCE_GROUP", "0") == "1"
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def shutdown(ok=True):
+    """Leave the group.  ok=True (clean exit): all ranks meet in a barrier first.  ok=False (this rank is unwinding an exception):
+    NO barrier -- the other ranks may never reach one -- the group is destroyed (aborted where the backend offers it) and the caller
+    re-raises, so the launcher sees the failure at once."""
     import torch.distributed as dist
     if _state["initialised_here"] and dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
+        if ok:
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            try:
+                pg = dist.distributed_c10d._get_default_group()
+                if hasattr(pg, "abort"):
+                    pg.abort()                              # RCCL: drop pending work instead of draining it
+                dist.destroy_process_group()
+            except Exception:
+                pass
         _state["initialised_here"] = False
 
 
@@ -88,24 +125,42 @@ def _store():
         return None
 
 
-def release_ranks(tag):
-    """Rank 0: publish that the single-rank stage `tag` is complete (see wait_for_rank0)."""
+class Rank0StageFailed(RuntimeError):
+    """Raised on the idle ranks when rank 0's single-rank stage raised (its own traceback is rank 0's)."""
+
+
+def release_ranks(tag, ok=True):
+    """Rank 0: publish that the single-rank stage `tag` is complete -- or, ok=False, that it failed (see wait_for_rank0)."""
     if not is_distributed():
         return
     st = _store()
     if st is not None:
-        st.set(f"aqg/{tag}", b"1")
+        st.set(f"aqg/{tag}", b"1" if ok else b"fail")
+
+
+@contextlib.contextmanager
+def single_rank_stage(tag):
+    """Rank 0 wraps its solitary work in this: the stage key is published on the way out WHATEVER happened, so the ranks parked in
+    wait_for_rank0(tag) never outlive a failure (they raise Rank0StageFailed)."""
+    try:
+        yield
+    except BaseException:
+        release_ranks(tag, ok=False)
+        raise
+    release_ranks(tag, ok=True)
 
 
 def wait_for_rank0(tag, poll_hours=240):
     """Ranks other than 0: host-side wait (rendezvous store, no collective in flight, so no watchdog) until rank 0 has
-    called release_ranks(tag).  Falls back to nothing when the store is unavailable -- the barrier that follows then waits, bounded
-    by AQG_DIST_TIMEOUT_S."""
+    published the stage `tag`; raises Rank0StageFailed if rank 0 failed in it.  Falls back to nothing when the store is
+    unavailable -- the barrier that follows then waits, bounded by AQG_DIST_TIMEOUT_S."""
     if not is_distributed():
         return
     st = _store()
     if st is not None:
         st.wait([f"aqg/{tag}"], datetime.timedelta(hours=poll_hours))
+        if bytes(st.get(f"aqg/{tag}")) == b"fail":
+            raise Rank0StageFailed(f"rank 0 failed in stage {tag}")
 
 
 def next_tag(prefix):

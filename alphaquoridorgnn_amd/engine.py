@@ -210,14 +210,30 @@ class BatchedSelfPlay:
         return self.counters()
 
     # ------------------------------------------------------------------ search only (pv_mcts_policy)
-    def search(self, root_states72):
+    def search(self, root_states72, check_saturation=True):
+        """pv_mcts_policy for G roots at once: (visits i32 [G, MAX_LEGAL], actions u8, count i32).
+        check_saturation (GNN evaluator): the fp16-range guard's word (counters[5]) is cleared before the search and read back after it
+        (one 4-byte copy: the callers read the visit counts back anyway); if a launch of this search met a value outside fp16 range its
+        evaluations were finite but not the network's, so the weight set is marked (model.mark_saturated), the engine switches to the
+        exact f32-input kernels and the search is repeated -- the caller never receives visit counts of clamped evaluations."""
         roots = torch.as_tensor(root_states72, dtype=torch.uint8).to(self.dev).contiguous().view(self.G, 72)
         self._roots = roots
-        if self.evaluator == "external":
-            _lib.check(self.lib.aqg_engine_set_roots(ctypes.byref(self.e), _lib.ptr(roots), self._stream()), "aqg_engine_set_roots")
-            self._external_sims()
-        else:
-            _lib.check(self.lib.aqg_engine_search(ctypes.byref(self.e), _lib.ptr(roots), self._stream()), "aqg_engine_search")
+        for attempt in range(2):
+            guarded = check_saturation and self.evaluator == "gnn" and not (self.e.gnn_flags & _lib.GNN_EXACT_F32)
+            if guarded:
+                self.t["counters"][5] = 0          # a cached engine (pv_mcts._engines) must not inherit an earlier search's word
+            if self.evaluator == "external":
+                _lib.check(self.lib.aqg_engine_set_roots(ctypes.byref(self.e), _lib.ptr(roots), self._stream()), "aqg_engine_set_roots")
+                self._external_sims()
+            else:
+                _lib.check(self.lib.aqg_engine_search(ctypes.byref(self.e), _lib.ptr(roots), self._stream()), "aqg_engine_search")
+            if not guarded or int(self.t["counters"][5].item()) == 0:
+                break
+            if self.model is not None and hasattr(self.model, "mark_saturated"):
+                self.model.mark_saturated(self.dev)
+            self._gnn_flags = _lib.GNN_EXACT_F32
+            self.e.gnn_flags = _lib.GNN_EXACT_F32
+            self.t["counters"][5] = 0
         visits = torch.empty((self.G, _lib.MAX_LEGAL), dtype=torch.int32, device=self.dev)
         actions = torch.empty((self.G, _lib.MAX_LEGAL), dtype=torch.uint8, device=self.dev)
         count = torch.empty((self.G,), dtype=torch.int32, device=self.dev)
@@ -389,12 +405,19 @@ class MultiSetSelfPlay:
         return tuple(torch.cat([p[j] for p in parts], 0) for j in range(3))
 
 
-def gather_history(states72, visits, z, group=None):
+def gather_history(states72, visits, z, group=None, force_collective=None):
     """The one exchange step per generation: all-gather the ragged (s, pi, z) tuples of every rank.
     Counts are gathered first, payloads are padded to the max count (RCCL needs equal sizes) and trimmed after.
-    Works on any torch.distributed backend (nccl == RCCL on ROCm; gloo in the CPU tests)."""
+    Works on any torch.distributed backend (nccl == RCCL on ROCm; gloo in the CPU tests).
+    force_collective (default: AQG_DIST_FORCE_GROUP=1): run the two collectives at world size 1 as well instead of returning the
+    inputs -- the RCCL code path on the one GPU a developer box has (the result is the same rows, bit for bit)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return states72, visits, z
+    if force_collective is None:
+        from .distributed import force_group
+        force_collective = force_group()
+    if dist.get_world_size(group) == 1 and not force_collective:
         return states72, visits, z
     W = dist.get_world_size(group)
     dev = states72.device

@@ -12,6 +12,7 @@ from shutil import copy
 import numpy as np
 import torch
 
+from . import _lib
 from . import pv_mcts
 from .constants import PV_NETWORK_PATH, BOARD_SIZE
 from .engine import BatchedSelfPlay
@@ -85,7 +86,28 @@ class BatchedMatch:
 
     def play(self, uniforms=None):
         """Play every game to the end.  uniforms: optional pair of float64 arrays [max_plies, G_first] (parity tests).
-        Returns the per-game points of player 0 in game order."""
+        Returns the per-game points of player 0 in game order.
+        fp16-range guard: the engines' counters are read after every ply anyway; if a split-kernel launch of either player met a value
+        outside fp16 range (counters()['gnn_saturated']) the moves so far were searched with clamped evaluations, so BOTH players are
+        marked (mark_saturated), every evaluation switches to the exact f32-input kernels and the match is replayed from ply 0 -- the
+        promotion decision of evaluate_network (evaluate_network.py:90-94) is never taken on evaluations that are not the networks'."""
+        while True:
+            points = self._play_once(uniforms)
+            if points is not None:
+                return points
+
+    def _switch_to_exact_kernels(self):
+        for m in self.players:
+            if hasattr(m, "mark_saturated"):
+                m.mark_saturated()
+        self._flags = [_lib.GNN_EXACT_F32 for _ in self.players]
+        for eng in self.engines:
+            if eng is not None:
+                eng._gnn_flags = _lib.GNN_EXACT_F32
+                eng.e.gnn_flags = _lib.GNN_EXACT_F32
+                eng.reset()
+
+    def _play_once(self, uniforms):
         live = [e is not None for e in self.engines]
         ply = 0
         while any(live):
@@ -96,7 +118,13 @@ class BatchedMatch:
                 eng.move(None if uniforms is None else uniforms[first][ply])
             ply += 1
             for first, eng in enumerate(self.engines):
-                if live[first] and (eng.counters()["active"] == 0 or ply >= eng.max_plies):
+                if not live[first]:
+                    continue
+                c = eng.counters()
+                if self.evaluator == "gnn" and c["gnn_saturated"] and not all(f & _lib.GNN_EXACT_F32 for f in self._flags):
+                    self._switch_to_exact_kernels()
+                    return None
+                if c["active"] == 0 or ply >= eng.max_plies:
                     live[first] = False
         points = []
         per = []

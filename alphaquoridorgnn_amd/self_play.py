@@ -100,6 +100,8 @@ def self_play(model=None, games=None, seed=None):
         c = eng.play_generation()
         print(f'\rSelf-play (rank {rank}: {c["finished"]}/{mine} games)', end='')
         st, vis, z = eng.history_tensors()
+    if distributed and os.environ.get("AQG_DIST_LOG") == "1" and rank == 0:
+        print(f'exchange step: backend={dist.get_backend()} world={world} collectives={"forced" if aqd.force_group() else "as needed"}')
     if distributed and dist.get_backend() != 'nccl':          # gloo (CPU tests): the exchange runs on host tensors
         st, vis, z = (x.cpu() for x in gather_history(st.cpu(), vis.cpu(), z.cpu()))
     else:
@@ -129,9 +131,12 @@ def main(argv=None):
     if args.sims is not None:
         pv_mcts.PV_EVALUATE_COUNT = args.sims
     try:
-        return self_play(games=args.games, seed=args.seed)
-    finally:
-        aqd.shutdown()
+        path = self_play(games=args.games, seed=args.seed)
+    except BaseException:
+        aqd.shutdown(ok=False)
+        raise
+    aqd.shutdown()
+    return path
 
 
 if __name__ == '__main__':

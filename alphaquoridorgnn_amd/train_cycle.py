@@ -39,8 +39,8 @@ def _evaluate_once():
     dist, on, rank = _dist()
     tag = aqd.next_tag("evaluate")
     if rank == 0:
-        promoted = evaluate_network()
-        aqd.release_ranks(tag)
+        with aqd.single_rank_stage(tag):           # the key is published even if the match raises: idle ranks wake up and raise too
+            promoted = evaluate_network()
     else:
         promoted = False
         aqd.wait_for_rank0(tag)          # host-side wait: no collective is pending while rank 0 plays the match
@@ -105,9 +105,11 @@ def main(argv=None):
             with open(os.path.join(args.result_dir, f"train_cycle.rank{rank}.json"), "w") as f:
                 json.dump({"rank": rank, "world": world, "promoted": promoted, "latest_sha256": digest,
                            "device": torch.cuda.current_device()}, f)
-        return promoted
-    finally:
-        aqd.shutdown()
+    except BaseException:
+        aqd.shutdown(ok=False)                      # no barrier on the way out of an exception: the other ranks may never reach one
+        raise
+    aqd.shutdown()
+    return promoted
 
 
 if __name__ == '__main__':

@@ -173,8 +173,8 @@ def train_network():
         from . import distributed as aqd
         tag = aqd.next_tag("train")
         if rank == 0:
-            _train_single_process()
-            aqd.release_ranks(tag)
+            with aqd.single_rank_stage(tag):       # published on failure too (value b"fail"): the idle ranks raise instead of waiting
+                _train_single_process()
         else:
             aqd.wait_for_rank0(tag)     # host-side wait on the rendezvous store: no collective is pending while rank 0 trains, so
                                         # the stage may outlast the process group's watchdog timeout (distributed.py)

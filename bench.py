@@ -311,7 +311,7 @@ def main():
                                                       _lib.ptr(value), gnn_flags, _lib.ptr(sat_word), _lib.stream_ptr(dev)), "fwd")
     # every variant is timed three times in interleaved order and its best time kept: a single pass right after the pools
     # were freed under-reported the exact-f32 kernel by 3.4x in the round-1 driver run (4.96 M vs 17 M boards/s here)
-    names = (("f32_mfma_exact", 1), ("f16_split_mm_8wave_x2", 6), ("f16_split_mm_4wave_x2", 5))
+    names = (("f32_mfma_exact", 1), ("f16_split_mm_8wave_x2", 6))
     variants = {n: {"ms_samples": []} for n, _ in names}
     for rep in range(3):
         for name, v in names:

@@ -34,11 +34,10 @@ extern "C" {
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
 /* tuning knobs: "trunk_variant" 0/1 = exact f32-input MFMA with 1/2 workgroups per CU, 3 = all-MFMA fp16 split trunk
- * (hi*hi + hi*lo + lo*hi: fp32-equivalent products; default = the 8-wave x 2-per-CU form, also selected by 6), 4 / 5 = the
- * 4-wave x 2-per-CU form, 7 = the pair form (one workgroup per CU, two boards per pass: measured slower, kept as evidence); "step_variant" 1/0 = one-load-round MCTS step / round-1 step, "step_fast_depth" = tree depth at which
+ * (hi*hi + hi*lo + lo*hi: fp32-equivalent products; default = the 8-wave x 2-per-CU form, also selected by 6); "step_variant" 1/0 = one-load-round MCTS step / round-1 step, "step_fast_depth" = tree depth at which
  * the fast step hands over to memory mode; "trunk_prio" = static wave priorities in the trunk (-1 = by launch size, default); "step_prio" / "heads_prio" 0..3 = wave
  * priority of the MCTS step / heads kernels (defaults 1 / 3); "step_waves" = games per step workgroup (4);
- * "fuse_heads" 1 = heads inside the trunk workgroup (measured slower, default 0); "train_fused" = form of the training step
+ * "train_fused" = form of the training step
  * (csrc/gcn_train.hip): 2 (default) one workgroup per position with every contraction in fp16 split precision on the 16-bit
  * matrix pipe (9x9 board; a position whose values leave fp16 range is redone in f32 inside the same launch, counted by
  * aqg_gcn_train_fallbacks), 1 one workgroup per position with f32-input MFMA, 0 the six-launch column-split chain, 3 = 2 with
@@ -97,7 +96,9 @@ int aqg_state_status(int board_size, const uint8_t* states72, int B, int plies_f
  *                32-deep k block (default trunk: layer 1 runs aggregate-first, (A_hat X) W1)
  *   WHH1, WHP2   the heads' matrices as fp16 hi/lo fragments;  TB  bias rows (15/16) b sqrt(deg) per layer and degree;
  *   GUARD [4]    thresholds of the trunk's fp16-range guard on the linear maps' outputs: [0] = (65504 - max |TB of layer 2|) / 2.07
- *                (below it layer 2's aggregate provably stays under 65504), [1] = 65504, [2..3] spare (ABI 8: the last four floats)
+ *                (below it layer 2's aggregate provably stays under 65504), [1] = 65504, [2..3] spare (ABI 8: the last four floats);
+ *                both are -1 (no maximum passes: every board is reported) when a trunk weight's fp16 hi half is not finite
+ *                (|W| (16/15) >= 65504, inf or NaN)
  * aqg_gcn_packed_floats() returns the total; aqg_gcn_pack_weights_host() fills a HOST buffer from the 14
  * state_dict tensors given as HOST float32 pointers in the key order of KEYS in INTEGRATION.md. */
 size_t aqg_gcn_packed_floats(int board_size);

@@ -114,6 +114,20 @@ def test_weight_packing_layout():
     assert n == GUARD + 4
     tb2 = 15.0 / 16.0 * np.sqrt(5.0) * np.abs(p["gcn_layers.1.bias"].astype(np.float64)).max()
     assert abs(out[GUARD] - (65504.0 - tb2) / 2.07) <= 1e-2 and out[GUARD + 1] == 65504.0 and not out[GUARD + 2:].any()
+    # a weight whose fp16 hi half is not finite (|W| / CQ >= 65504, inf, NaN) would give NaN columns that the float maxima of the
+    # tracking build skip: such a set is packed with NEGATIVE thresholds -- every board is reported
+    for key, idx, val in (("gcn_layers.1.lin.weight", (3, 7), 7e4), ("gcn_layers.2.lin.weight", (100, 1), -7e4), ("gcn_layers.1.lin.weight", (0, 0), np.nan),
+                          ("gcn_layers.0.lin.weight", (5, 2), np.inf), ("gcn_layers.1.lin.weight", (3, 7), 6.0e4)):
+        pb = {k: v.copy() for k, v in p.items()}
+        pb[key][idx] = val
+        hb = [np.ascontiguousarray(pb[k], dtype=np.float32) for k in og.KEYS]
+        ab = (ctypes.c_void_p * 14)(*[h.ctypes.data_as(ctypes.c_void_p) for h in hb])
+        ob = np.zeros(n, dtype=np.float32)
+        assert lib.aqg_gcn_pack_weights_host(9, ab, ob.ctypes.data_as(ctypes.c_void_p)) == 0
+        if val == 6.0e4:           # 6.0e4 / CQ = 64,000: still a finite fp16
+            assert ob[GUARD] > 0 and ob[GUARD + 1] == 65504.0
+        else:
+            assert ob[GUARD] == -1.0 and ob[GUARD + 1] == -1.0, (key, val)
     CQ = 15.0 / 16.0                                                       # scale of the default trunk's activation image
     wf2 = out[WF2:WF2 + 128 * 128].reshape(4, 2, 8, 64, 4)                 # [wave][ntile][s4][lane][i]
     for (w, j, s4, lane, i) in [(0, 0, 0, 0, 0), (3, 1, 7, 63, 3), (2, 0, 5, 17, 2), (1, 1, 2, 40, 1)]:
@@ -250,6 +264,50 @@ def test_multi_rank_entry_under_torchrun_gloo(tmp_path):
     res = subprocess.run(cmd, env=env, cwd=str(tmp_path), timeout=300, capture_output=True, text=True)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert (tmp_path / "entry.0.ok").exists() and (tmp_path / "entry.1.ok").exists()
+
+
+_FAIL_WORKER = r"""
+import os, sys, time
+import torch.distributed as dist
+from alphaquoridorgnn_amd import distributed as aqd
+rank, world = aqd.init_from_env()
+t0 = time.time()
+try:
+    tag = aqd.next_tag("train")
+    if rank == 0:
+        with aqd.single_rank_stage(tag):
+            time.sleep(0.5)
+            raise ValueError("rank 0 failed inside its solitary stage")
+    else:
+        aqd.wait_for_rank0(tag)
+    dist.barrier()
+except BaseException as e:
+    open(f"fail.{rank}.txt", "w").write(f"{type(e).__name__} {time.time() - t0:.2f}")
+    aqd.shutdown(ok=False)
+    raise
+aqd.shutdown()
+"""
+
+
+def test_multi_rank_entry_failure_in_single_rank_stage(tmp_path):
+    """rank 0 raising inside a single-rank stage (training / evaluation) must end the job in seconds with ITS exception:
+    the stage key is published with value b'fail' on the way out, the idle rank wakes up in wait_for_rank0 and raises
+    Rank0StageFailed, and neither rank enters a barrier on the error path (shutdown(ok=False)) -- before, rank 0 sat in
+    shutdown()'s barrier until AQG_DIST_TIMEOUT_S and the others in store.wait for hours."""
+    import time
+    script = tmp_path / "fail_worker.py"
+    script.write_text(_FAIL_WORKER)
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""), AQG_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + (os.getpid() + 13) % 2000), str(script)]
+    t0 = time.time()
+    res = subprocess.run(cmd, env=env, cwd=str(tmp_path), timeout=300, capture_output=True, text=True)
+    assert res.returncode != 0
+    assert time.time() - t0 < 120, "the job must not wait for a collective timeout"
+    f0, f1 = (tmp_path / "fail.0.txt").read_text().split(), (tmp_path / "fail.1.txt").read_text().split()
+    assert f0[0] == "ValueError" and f1[0] == "Rank0StageFailed"
+    assert float(f0[1]) < 30 and float(f1[1]) < 30
+    assert "rank 0 failed inside its solitary stage" in res.stderr + res.stdout
 
 
 def test_self_play_sharding_arithmetic():
@@ -411,7 +469,7 @@ def test_set_option_names_ranges_and_errors():
     from alphaquoridorgnn_amd import _lib
     lib = _lib.load()
     defaults = {"trunk_variant": 3, "heads_prio": 3, "trunk_prio": -1, "trunk_grid": 0, "trunk_phase_delay": 100, "trunk_delay_min_boards": 2048,
-                "step_prio": 1, "step_waves": 4, "step_variant": 1, "step_fast_depth": None, "fuse_heads": 0, "train_fused": 2, "use_graph": 1,
+                "step_prio": 1, "step_waves": 4, "step_variant": 1, "step_fast_depth": None, "train_fused": 2, "use_graph": 1,
                 "profile_trunk": 0}
     header = open(os.path.join(REPO, "include", "aqgnn.h")).read()
     integration = open(os.path.join(REPO, "INTEGRATION.md")).read()
@@ -420,7 +478,7 @@ def test_set_option_names_ranges_and_errors():
         assert f"`{name}`" in integration, f"{name} is not listed in INTEGRATION.md"
         if value is not None:
             assert lib.aqg_set_option(name.encode(), value) == 0, name
-    for name, bad in (("trunk_variant", 2), ("trunk_variant", 8), ("trunk_phase_delay", -1), ("step_fast_depth", 62), ("train_fused", 4)):
+    for name, bad in (("trunk_variant", 2), ("trunk_variant", 4), ("trunk_variant", 7), ("trunk_variant", 8), ("trunk_phase_delay", -1), ("step_fast_depth", 62), ("train_fused", 4)):
         assert lib.aqg_set_option(name.encode(), bad) != 0, (name, bad)
         assert lib.aqg_last_error()
     assert lib.aqg_set_option(b"no_such_option", 1) != 0 and b"no_such_option" in lib.aqg_last_error()
