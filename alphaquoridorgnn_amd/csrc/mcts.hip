@@ -65,6 +65,26 @@ __device__ __forceinline__ float wave_max_dpp(float x) {       // max over the 6
     x = step(x, dpp_i<0x143, 0xc>(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x)));    // row_bcast31 -> rows 2, 3
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
+// The same maximum as six v_max_f32 with DPP operands (hipcc makes v_mov_dpp + a canonicalising v_max + v_max of each builtin step: 24
+// instructions and their wait states on the step kernel's per-level chain).  A DPP operand needs two wait states behind the VALU write
+// of its source: s_nop 1 between the steps (nothing is padded inside an asm statement).
+__device__ __forceinline__ float wave_max_dpp_asm(float x) {
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
 __device__ __forceinline__ int wave_sum_dpp(int x) {
     x += dpp_i<0xB1, 0xf>(0, x);
     x += dpp_i<0x4E, 0xf>(0, x);
@@ -98,7 +118,8 @@ struct alignas(32) NodeRec {
     uint32_t action;   // action that led to this node (0xFF for the root)
     float q;           // f32(-w / n) as PUCT adds it (pv_mcts.py:74), 0 while n == 0: maintained by every writer of (w, n), so the
                        // descent reads it with the record instead of doing a float64 division per tree level on its critical path
-    uint32_t pad;
+    float cp;          // f32(C_PUCT * p), the first product of PUCT's exploration term (pv_mcts.py:75, evaluated left to right in f32):
+                       // written with p, so the descent's per-level chain starts one multiply later
 };
 static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
 
@@ -174,7 +195,7 @@ __global__ void engine_begin_move_kernel(aqg_engine e) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= e.num_games || !e.game_active[g]) return;
     NodeRec root;
-    root.w = 0.0; root.p = 0.f; root.n = 0; root.kids = 0; root.action = 0xFF; root.q = 0.f; root.pad = 0;
+    root.w = 0.0; root.p = 0.f; root.n = 0; root.kids = 0; root.action = 0xFF; root.q = 0.f; root.cp = 0.f;
     game_nodes(e, g)[0] = root;
     e.node_count[g] = 1;
     const int k = e.slot_game[g];                  // the game this slot is playing
@@ -381,7 +402,7 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
             const int i = lane + 64 * r;
             if (i < cnt) {
                 NodeRec c;
-                c.w = 0.0; c.p = pl[r]; c.n = 0; c.kids = 0; c.action = oa[r]; c.q = 0.f; c.pad = 0;
+                c.w = 0.0; c.p = pl[r]; c.n = 0; c.kids = 0; c.action = oa[r]; c.q = 0.f; c.cp = e.c_puct * pl[r];
                 nodes[first + i] = c;
             }
         }
@@ -518,7 +539,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
                 const int i = lane + 64 * r;
                 if (i < cnt_new) {
                     NodeRec c;
-                    c.w = 0.0; c.p = pl[r]; c.n = 0; c.kids = 0; c.action = oa[r]; c.q = 0.f; c.pad = 0;
+                    c.w = 0.0; c.p = pl[r]; c.n = 0; c.kids = 0; c.action = oa[r]; c.q = 0.f; c.cp = e.c_puct * pl[r];
                     nodes[first_new + i] = c;
                 }
             }
@@ -569,6 +590,18 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     STEP_STAMP(1)
 
     // ---------------- descent (pv_mcts.py:33-66 via :69-78)
+    // A tree level is one dependent chain -- children arrive -> scores -> arg-max -> the chosen child's range -> next fetch -- and the
+    // step kernel is one wave per SIMD, so everything that does NOT depend on the children is moved off that chain:
+    //   * t = sum of the children's visit counts (pv_mcts.py:71) is the parent's own n minus one -- a node is visited once when it is
+    //     expanded and once more for every descent into a child (pv_mcts.py:49-50, :62-64) -- so sqrt(t) is formed from the parent's
+    //     record while the children's loads are in flight (no wave reduction, no square root behind the loads);
+    //   * C_PUCT * p comes with the record (NodeRec::cp);
+    //   * the pending backup patches the one child that lies on the old path with n + 1 and the q its own lane already holds; its w
+    //     is never needed here: if the new path stays on the old one, lane d already owns that node's updated (w, n) -- bw, bn;
+    //   * the next level's children are requested as soon as the chosen child's range is known; next() of the game state, the path
+    //     bookkeeping and the chosen child's statistics follow behind the loads;
+    //   * validity is a scalar mask, slots beyond the node's child count are skipped by scalar branches (no exec-mask regions), the
+    //     wave maximum is six v_max_f32 with DPP operands.
     QState s = uniform_state(s_loaded);
     bool regs = true;                 // round-1 / register copies are current (false after a fall-back to memory)
     if (flag == 1 && !fast_old) {
@@ -580,97 +613,103 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     int node = 0, depth = 0;
     int mynode = 0;                   // lane d: new path node at depth d ...
     double nw = 0.0; int nn = 0;      // ... and its current (w, n), pending updates included
+    const bool pend0 = flag == 1 && fast_old;                        // (wave-uniform) the old path's backup is pending in registers
     if (lane == 0) {
         path[0] = 0;
-        if (regs) { nw = (flag == 1 && fast_old) ? bw : rootrec.w; nn = (flag == 1 && fast_old) ? bn : rootrec.n; }
+        if (regs) { nw = pend0 ? bw : rootrec.w; nn = pend0 ? bn : rootrec.n; }
     }
-    bool onpath = flag == 1 && fast_old;     // the current node IS the old path's node at this depth
+    bool onpath = pend0;              // the current node IS the old path's node at this depth
     int terminal = 0;
     double tvalue = 0.0;
     uint32_t kids = regs ? ((onpath && depth_old == 0) ? kids_new : rootrec.kids) : nodes[0].kids;
-    // children of the current node, fetched one level ahead of their use: the root's come from round 1, the old leaf's are
-    // the records just built, everything else is one dependent load round per level
+    kids = (uint32_t)__builtin_amdgcn_readfirstlane((int)kids);
+    // n of the current node with the pending backup applied (lane 0 holds the root's)
+    int npar = __builtin_amdgcn_readfirstlane(regs ? (pend0 ? bn : rootrec.n) : nodes[0].n);
+    // children of the current node, fetched one level ahead of their use: the root's come from round 1, everything else is one
+    // dependent load round per level.  All three slots are requested whatever the child count (lanes / slots beyond it read the
+    // last child, or node 0 for an unexpanded child: same cache lines, and no conditional assignment for the compiler to merge with
+    // copies behind an s_waitcnt at the loop's back edge).  The records are never modified in registers: the pending backup's
+    // patch goes into temporaries.
     NodeRec rec[3];
-    auto fetch_children = [&](uint32_t k, bool built_now) {
+    auto fetch_children = [&](uint32_t k) {
         const int cnt = (int)(k >> 24), first = (int)(k & 0xFFFFFF);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int i = lane + 64 * r;
-            if (built_now) { rec[r].w = 0.0; rec[r].p = pl[r]; rec[r].n = 0; rec[r].kids = 0; rec[r].action = oa[r]; rec[r].q = 0.f; }
-            else if (i < cnt) rec[r] = nodes[first + i];
-            else { rec[r].w = 0.0; rec[r].p = 0.f; rec[r].n = 0; rec[r].kids = 0; rec[r].action = 0; rec[r].q = 0.f; }
-        }
+        for (int r = 0; r < 3; ++r) rec[r] = nodes[first + max(min(lane + 64 * r, cnt - 1), 0)];
     };
-    if (regs && onpath && depth_old == 0) fetch_children(kids, true);
-    else if (regs) {
+    if (regs) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) rec[r] = rc[r];
-    } else fetch_children(kids, false);
+    } else fetch_children(kids);
+    bool at_old_leaf = false;
     for (;;) {
         const bool lose = is_lose<N>(s), draw = is_draw(s, e.plies_for_draw);
         if (lose || draw) { tvalue = lose ? -1.0 : 0.0; terminal = 1; break; }      // pv_mcts.py:35-42
         const int cnt = (int)(kids >> 24), first = (int)(kids & 0xFFFFFF);
         if (cnt == 0) break;                                                         // pv_mcts.py:45 unexpanded leaf
-        // the old path's child of this node: backup delta and (if it is the old leaf) its new child range, in registers
-        const bool patch = regs && onpath && depth < depth_old;
-        const int pchild = patch ? __builtin_amdgcn_readlane(pnode, (depth + 1) & 63) : -1;
-        // its exploitation term after the pending backup: lane depth + 1 computed it from that node's own record (one division per
-        // step, started before the descent); at the root it is formed here from the round-1 copy, so that level 0 does not wait
-        // for the second load round
-        const float pq = (patch && depth > 0) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bq), (depth + 1) & 63)) : 0.f;
-        int t = 0;
+        // The current node is the old leaf, expanded a moment ago: handled behind the loop (no record is needed there)
+        if (regs && onpath && depth == depth_old) { at_old_leaf = true; break; }
+        uint32_t kids_n; int action, cn, besti; double cw;
+        {
+            // the old path's child of this node: its index among these children, and its exploitation term after the pending backup --
+            // lane depth + 1 computed it from that node's own record (one division per step, started before the descent); at the root
+            // it is formed below from the round-1 copy, so that level 0 does not wait for the second load round
+            const bool patch = regs && onpath && depth < depth_old;
+            const int pidx = patch ? __builtin_amdgcn_readlane(pnode, (depth + 1) & 63) - first : -1;
+            const float pq = (patch && depth > 0) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bq), (depth + 1) & 63)) : 0.f;
+            const float st = sqrtf((float)(npar - 1));            // == f32(math.sqrt(t)), see game_select; t = npar - 1
+            float sc[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int neff[3] = {rec[0].n, rec[1].n, rec[2].n};
+            uint32_t keff[3] = {rec[0].kids, rec[1].kids, rec[2].kids};
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int i = lane + 64 * r;
-            if (i < cnt) {
-                if (first + i == pchild) {
-                    rec[r].w += ((depth_old - (depth + 1)) & 1) ? -v_old : v_old;
-                    rec[r].n += 1;
-                    rec[r].q = depth > 0 ? pq : q_of(rec[r].w, rec[r].n);
-                    if (depth + 1 == depth_old) rec[r].kids = kids_new;
-                }
-                t += rec[r].n;
-            }
-        }
-        t = wave_sum_dpp(t);
-        const float st = sqrtf((float)t);                     // == f32(math.sqrt(t)), see game_select
-        float sc[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int i = lane + 64 * r;
-            sc[r] = -INFINITY;
-            if (64 * r < cnt) {                                // (wave-uniform: most nodes below the root have < 64 children)
-                if (i < cnt) {
-                    const float u = ((e.c_puct * rec[r].p) * st) / (float)(1 + rec[r].n);
-                    sc[r] = rec[r].q + u;                      // q = f32(-w / n) travels with the record (NodeRec::q)
+            for (int r = 0; r < 3; ++r) {
+                if (64 * r < cnt) {                                // (scalar branch: most nodes below the root have < 64 children)
+                    float q = rec[r].q;                            // q = f32(-w / n) travels with the record (NodeRec::q)
+                    if (patch && (pidx >> 6) == r) {               // (scalar branch) this slot holds the old path's child
+                        const bool me = lane == (pidx & 63);
+                        if (depth == 0) {
+                            if (me) q = q_of(rec[r].w + (((depth_old - 1) & 1) ? -v_old : v_old), rec[r].n + 1);
+                        } else q = me ? pq : q;
+                        neff[r] += me ? 1 : 0;
+                        if (depth + 1 == depth_old) keff[r] = me ? kids_new : keff[r];
+                    }
+                    const float u = (rec[r].cp * st) / (float)(1 + neff[r]);
+                    sc[r] = (lane + 64 * r < cnt) ? q + u : -INFINITY;
                 }
             }
+            // np.argmax: the first index of the maximum.  Wave maximum by DPP, then the lowest child index holding it from up to three
+            // ballots (children lane, lane + 64, lane + 128 in that order), masked to the node's children.  NaN scores never equal the
+            // maximum; if nothing matches (all NaN) child 0 is taken, as before.
+            const float best = wave_max_dpp_asm(fmaxf(fmaxf(sc[0], sc[1]), sc[2]));
+            const uint64_t v0 = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+            const uint64_t m0 = __ballot(sc[0] == best) & v0;
+            besti = 0;
+            if (m0) besti = __builtin_ctzll(m0);
+            else if (cnt > 64) {
+                const uint64_t v1 = cnt >= 128 ? ~0ull : ((1ull << (cnt - 64)) - 1ull);
+                const uint64_t m1 = __ballot(sc[1] == best) & v1;
+                if (m1) besti = 64 + __builtin_ctzll(m1);
+                else if (cnt > 128) {
+                    const uint64_t m2 = __ballot(sc[2] == best) & ((1ull << (cnt - 128)) - 1ull);
+                    if (m2) besti = 128 + __builtin_ctzll(m2);
+                }
+            }
+            besti = __builtin_amdgcn_readfirstlane(besti);
+            const int slot = besti >> 6, src = besti & 63;      // wave-uniform: the winner's fields come by v_readlane
+            uint32_t wlo, whi;
+            auto pick = [&](const NodeRec& c, uint32_t k, int n) {
+                kids_n = (uint32_t)__builtin_amdgcn_readlane((int)k, src);
+                action = __builtin_amdgcn_readlane((int)c.action, src);
+                cn = __builtin_amdgcn_readlane(n, src);
+                const uint64_t wbits = __builtin_bit_cast(uint64_t, c.w);
+                wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wbits, src);
+                whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wbits >> 32), src);
+            };
+            if (slot == 0) pick(rec[0], keff[0], neff[0]); else if (slot == 1) pick(rec[1], keff[1], neff[1]); else pick(rec[2], keff[2], neff[2]);
+            cw = __builtin_bit_cast(double, ((uint64_t)whi << 32) | wlo);   // (used only if the path ends on a terminal node off the old path)
+            onpath = patch && besti == pidx;                    // the new path follows the old one a level further
         }
-        // np.argmax: the first index of the maximum.  Wave maximum by DPP, then the lowest child index holding it from three
-        // ballots (children lane, lane + 64, lane + 128 in that order).  NaN scores never equal the maximum; if nothing
-        // matches (all NaN) child 0 is taken, as before.
-        const float best = wave_max_dpp(fmaxf(fmaxf(sc[0], sc[1]), sc[2]));
-        const uint64_t m0 = __ballot(lane < cnt && sc[0] == best), m1 = __ballot(lane + 64 < cnt && sc[1] == best),
-                       m2 = __ballot(lane + 128 < cnt && sc[2] == best);
-        const int besti = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 + __builtin_ctzll(m2) : 0));
-        const int slot = besti >> 6, src = besti & 63;          // wave-uniform: the winner's fields come by v_readlane
-        const uint32_t k_sel = slot == 0 ? rec[0].kids : (slot == 1 ? rec[1].kids : rec[2].kids);
-        const uint32_t a_sel = slot == 0 ? rec[0].action : (slot == 1 ? rec[1].action : rec[2].action);
-        const double w_sel = slot == 0 ? rec[0].w : (slot == 1 ? rec[1].w : rec[2].w);
-        const int n_sel = slot == 0 ? rec[0].n : (slot == 1 ? rec[1].n : rec[2].n);
-        kids = (uint32_t)__builtin_amdgcn_readlane((int)k_sel, src);
-        const int action = __builtin_amdgcn_readlane((int)a_sel, src);
-        // the chosen child's current statistics travel to lane depth + 1 (used only if the path ends on a terminal node)
-        const uint64_t wbits = __builtin_bit_cast(uint64_t, w_sel);
-        const double cw = __builtin_bit_cast(double, ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wbits >> 32), src) << 32) |
-                                                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wbits, src));
-        const int cn = __builtin_amdgcn_readlane(n_sel, src);
         node = first + besti;
-        onpath = onpath && depth < depth_old && node == pchild;
-        s = next_state<N>(s, action);
         ++depth;
-        if (lane == 0) path[depth] = node;
-        if (lane == (depth & 63) && depth < 64) { mynode = node; nw = cw; nn = cn; }
         // next level's children
         if (regs && depth >= fast_depth) {          // hand over to memory: flush what is pending, fence, go on reading memory
             flush_old();
@@ -679,11 +718,34 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             regs = false;
         }
+        kids = kids_n;
+        npar = cn;
         // (Requesting the old path's next child block speculatively, before the scores are computed, was tried: the level
-        //  got 14 % SLOWER -- its arithmetic, not its load, is the long pole, and a wrong guess costs a second round.)
-        fetch_children(kids, regs && onpath && depth == depth_old);
+        //  got 14 % SLOWER -- a wrong guess costs a second round.)
+        fetch_children(kids);
+        // ... and behind the loads: the game state, the path, the chosen child's statistics for lane `depth`
+        s = next_state<N>(s, action);
+        if (lane == 0) path[depth] = node;
+        const bool stay = regs && onpath;
+        if (lane == (depth & 63) && depth < 64) { mynode = node; nw = stay ? bw : cw; nn = stay ? bn : cn; }
 #ifdef AQG_STAMP
         if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[6] += 1;     // levels descended
+#endif
+    }
+    if (at_old_leaf) {
+        // The descent has followed the old path down to the old leaf, whose children are the records built above (n = 0, q = 0).  Their
+        // visit counts sum to t = 0, so every score is 0 + (cp * 0) / 1 = 0 (or NaN for a NaN prior: never the maximum) and np.argmax
+        // takes the FIRST child (pv_mcts.py:72-78) -- no record is needed to know that, and the child is a fresh leaf
+        // (or a terminal position): the descent ends one level below.
+        node = (int)(kids & 0xFFFFFF);
+        s = next_state<N>(s, __builtin_amdgcn_readlane((int)oa[0], 0));
+        ++depth;
+        if (lane == 0) path[depth] = node;
+        if (lane == (depth & 63) && depth < 64) { mynode = node; nw = 0.0; nn = 0; }
+        const bool lose = is_lose<N>(s), draw = is_draw(s, e.plies_for_draw);
+        if (lose || draw) { tvalue = lose ? -1.0 : 0.0; terminal = 1; }
+#ifdef AQG_STAMP
+        if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[6] += 1;
 #endif
     }
 #ifdef AQG_STAMP

@@ -9,8 +9,16 @@ all-gather of the (s, pi, z) tuples over RCCL/xGMI (configs[3]).  Weak scaling: 
 
 `--backend gloo` swaps RCCL for gloo (host tensors) so that the N > 1 path can be rehearsed with several ranks on one GPU.
 
-Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  gnn_forward  : configs[1] -- pv_network_gnn forward at B=4096 synthetic boards, boards/s (HIP events)
+Rank 0 prints ONE JSON line, numbers only (< 6 KB, so that a driver keeping an 8 KB tail keeps every leg); what each key means, how
+it is measured and what bounds it is written HERE and in DESIGN.md section 5 (`notes_ref`).  Besides the contract keys it carries
+  gnn_forward  : configs[1] -- pv_network_gnn forward (trunk + heads) at B = 4,096 synthetic boards, boards/s from HIP events; the same
+                 at 16,384 and 65,536 boards; `tracking_build` = the trunk build a weight set WITHOUT a proven fp16
+                 range runs (flags 0: float-maximum range guard), `proven_build` = the one this run's initialisation-scale weights run
+                 (AQG_GNN_RANGE_PROVEN: the headline uses it); `f32_mfma_exact` = the exact f32-input MFMA trunk; mfma_frac against the
+                 fp16 / 3 split roof, hbm_frac_survey_formula = boards/s x 169,760 B / 8 TB/s (effective: activations stay in LDS)
+  rccl_group_alive : the headline generation in three fresh processes -- no process group / a world-size-1 backend-nccl (RCCL) group
+                 created BEFORE the four game-set streams / created AFTER them -- with the generation's exchange step running through
+                 the communicator (engine.gather_history, collectives forced): games/s each, and the ratios to `none`
   legal_mask   : SURVEY 8(d)'s second kernel -- batched State.legal_actions() at 4,096 and 65,536 states: states/s from per-launch
                  HIP event pairs (median / min / max), hbm_frac = states/s x 100 B / 8 TB/s (<< 1, stated), the CPU oracle beside it
   step_kernel  : the fused MCTS step (engine_step_fast_kernel): latency-bound, so its entry is us per launch at 512 and
@@ -48,7 +56,7 @@ HBM_BYTES_PER_BOARD = 169760                                         # SURVEY 8(
 PEAK_F32_MFMA = 157.3e12                                             # MI355X_MICROARCH.md: f32-input MFMA
 PEAK_F16_MFMA = 2500.0e12                                            # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
 SPLIT_TERMS = 3                                                      # hi*hi + hi*lo + lo*hi per f32 product
-TRUNK_MFMA_PER_BOARD = 4 * (12 + 2 * 144 + 3 * 40)                   # 16x16x32 fp16 MFMAs issued per board (incl. aggregation, padding)
+TRUNK_MFMA_PER_BOARD = 8 * (6 + 2 * 72 + 2 * 20)                     # 1,520 16x16x32 fp16 MFMAs issued per board (layer 1, linear maps, aggregations, padding)
 PEAK_HBM = 8.0e12
 # Compulsory global traffic of the default trunk per board: the 72-byte record (24 inside the engine) in, the 512-byte pooled
 # row out; the weight fragments are served by the L2 (hit rate 97.5-99.5 %, profiles/r03_pmc_summary.csv).  PMC counters
@@ -131,9 +139,79 @@ def cpu_baseline(sims, mean_plies, budget_s=15.0, workers=None):
         total_plies += int(pl)
     return {"value": plies_per_s / max(mean_plies, 1.0), "unit": "games/s", "cores": workers, "kind": "port",
             "sims_per_s": plies_per_s * sims,
-            "sample": f"{workers} processes x {budget_s:.0f} s of sequential {sims}-sims/move self-play each ({total_plies} plies in total; numpy-fp64 "
-                      f"GNN oracle + C rules oracle, one thread per process); games/s = summed plies/s / {mean_plies:.1f} mean plies per game "
-                      "of the GPU run"}
+            "sample": f"{workers} procs x {budget_s:.0f} s sequential {sims}-sims/move self-play ({total_plies} plies), oracle GNN fp64 + C rules"}
+
+
+_RCCL_ORDERS = ("none", "before", "after")
+
+
+def rccl_child(order, games, sims, sets):
+    """One fresh process of the `rccl_group_alive` leg: the headline generation with no process group (`none`), or with a
+    world-size-1 backend-nccl group whose RCCL communicator is created BEFORE / AFTER the engine's game-set streams; the exchange
+    step of every generation goes through engine.gather_history (with the group: two real collectives on device tensors).
+    Prints one small JSON line (not the contract line)."""
+    if order != "none":
+        os.environ["AQG_DIST_FORCE_GROUP"] = "1"
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from alphaquoridorgnn_amd import distributed as aqd
+    from alphaquoridorgnn_amd.engine import MultiSetSelfPlay, gather_history
+    from alphaquoridorgnn_amd.pv_network_gnn import GNNNetwork
+
+    def make_group():
+        aqd.init_from_env()                                     # backend nccl, device_id = this GPU (AQG_DIST_FORCE_GROUP)
+        t = torch.ones((4,), device=dev)
+        out = torch.empty((4,), device=dev)
+        dist.all_gather_into_tensor(out, t)                     # the communicator (and its streams) exist from here on
+        torch.cuda.synchronize()
+    if order == "before":
+        make_group()
+    torch.manual_seed(0)
+    model = GNNNetwork().to(dev).eval()
+    eng = MultiSetSelfPlay(model, num_games=games, sims=sims, num_sets=sets, seed=1000)
+    if order == "after":
+        make_group()
+
+    def generation():
+        eng.reset()
+        c = eng.play_generation()
+        st, vis, z = gather_history(*eng.history_tensors())
+        return c["finished"], int(st.shape[0])
+    generation()                                                # untimed: graph capture, clocks
+    torch.cuda.synchronize()
+    t0 = time.time()
+    fin = 0
+    for _ in range(2):
+        f, rows = generation()
+        fin += f
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(json.dumps({"order": order, "games_per_s": fin / dt, "rows": rows,
+                      "backend": dist.get_backend() if dist.is_initialized() else None}))
+    if dist.is_initialized():
+        aqd.shutdown()
+
+
+def rccl_group_alive_leg(games, sims, sets):
+    """Three fresh processes (see rccl_child), one after the other, BEFORE this process touches the GPU."""
+    import subprocess
+    leg = {"games_per_s": {}}
+    for order in _RCCL_ORDERS:
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-child", order, "--games", str(games), "--sims", str(sims),
+                                  "--sets", str(sets)], capture_output=True, text=True, timeout=600)
+            rec = json.loads(out.stdout.strip().splitlines()[-1])
+            leg["games_per_s"][order] = rec["games_per_s"]
+            leg["rows"] = rec["rows"]
+            if order != "none":
+                leg["backend"] = rec["backend"]
+        except Exception as e:                                  # the leg must never take the contract line down with it
+            leg["games_per_s"][order] = None
+            leg["error"] = f"{order}: {type(e).__name__}"
+    base = leg["games_per_s"].get("none")
+    if base:
+        leg["ratio_to_none"] = {k: (v / base if v else None) for k, v in leg["games_per_s"].items() if k != "none"}
+    return leg
 
 
 def legal_mask_leg(dev, lib, _lib, synth_states):
@@ -141,8 +219,42 @@ def legal_mask_leg(dev, lib, _lib, synth_states):
     one wavefront per state, mask + ordered list + count written.  Every launch sits between its own HIP event pair on the
     launch stream, so a host hiccup between launches shows up as ONE long sample (max_us) instead of inflating the mean
     (round 2's unexplained '481 us at B = 512' was the mean of 200 back-to-back launches behind one event pair)."""
-    leg = {"kernel": "legal_actions_kernel<9> (one wavefront per state: placement masks + touch-count prefilter on the scalar unit, two jump-aware "
-                     "flood fills per candidate wall, list order by ballots)", "bound": "integer ALU / latency (not HBM)", "batches": {}}
+    leg = {"kernel": "legal_actions_kernel<9>", "bound": "integer ALU / latency (not HBM)", "batches": {}}
+    for B in (4096, 65536):
+        st = synth_states(B, seed=1, dev=dev)
+        mask = torch.empty((B, 209), dtype=torch.uint8, device=dev)
+        order = torch.empty((B, 136), dtype=torch.uint8, device=dev)
+        count = torch.empty((B,), dtype=torch.int32, device=dev)
+
+        def legal():
+            _lib.check(lib.aqg_legal_actions(9, _lib.ptr(st), B, _lib.ptr(mask), _lib.ptr(order), _lib.ptr(count), _lib.stream_ptr(dev)), "legal")
+        for _ in range(10):
+            legal()
+        torch.cuda.synchronize()
+        n = 100
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        for i in range(n):
+            legal()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        us = np.asarray([ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(n)])
+        med = float(np.median(us))
+        leg["batches"][str(B)] = {"us_per_launch_median": med, "us_min": float(us.min()), "us_max": float(us.max()),
+                                  "states_per_s": B / (med * 1e-6), "hbm_frac": B / (med * 1e-6) * LEGAL_BYTES_PER_STATE / PEAK_HBM,
+                                  "mean_legal_actions": float(count.float().mean()),
+                                  "mean_walls_on_board": float((st[:, 4:68] != 0).sum(1).float().mean())}
+    leg["_sample"] = synth_states(4096, seed=1, dev=dev).cpu().numpy()     # handed to the cpu_baseline leg, removed before printing
+    leg["reference_python_states_per_s_per_core"] = 1e3 / REF_LEGAL_MS_PER_STATE_PY
+    return leg
+
+
+def legal_mask_leg(dev, lib, _lib, synth_states):
+    """SURVEY 8(d) second kernel: batched State.legal_actions() (game_logic.py:103-117, BFS :309-348) -- legal_actions_kernel<9>,
+    one wavefront per state, mask + ordered list + count written.  Every launch sits between its own HIP event pair on the
+    launch stream, so a host hiccup between launches shows up as ONE long sample (max_us) instead of inflating the mean
+    (round 2's unexplained '481 us at B = 512' was the mean of 200 back-to-back launches behind one event pair)."""
+    leg = {"kernel": "legal_actions_kernel<9>", "bound": "integer ALU / latency (not HBM)", "batches": {}}
     for B in (4096, 65536):
         st = synth_states(B, seed=1, dev=dev)
         mask = torch.empty((B, 209), dtype=torch.uint8, device=dev)
@@ -195,13 +307,19 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the step-kernel / slot-refill / training legs (profiling runs)")
     ap.add_argument("--large-games", type=int, default=16384,
                     help="extra single-GPU leg: one generation at this many concurrent games (north star: >= 10k); 0 = skip")
+    ap.add_argument("--rccl-child", default=None, choices=_RCCL_ORDERS, help="internal: one process of the rccl_group_alive leg")
     args = ap.parse_args()
+    if args.rccl_child:
+        return rccl_child(args.rccl_child, args.games, args.sims, args.sets)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rccl_leg = None
+    if world == 1 and not args.no_extra_legs and dist.is_nccl_available():
+        rccl_leg = rccl_group_alive_leg(args.games, args.sims, args.sets)     # before this process creates its own GPU context
     local = local % max(torch.cuda.device_count(), 1)        # gloo rehearsal: more ranks than GPUs share the card
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -295,33 +413,43 @@ def main():
     total_games, total_evals = float(tt[1]), float(tt[2])
     mean_plies = positions / max(total_games / max(args.steps, 1), 1.0)   # gathered positions of the last step / games per step
 
-    # ---- configs[1]: GNN forward, B = 4096 synthetic boards, HIP events on the launch stream (rank-local)
+    # ---- configs[1]: GNN forward (trunk + heads), B = 4096 synthetic boards, HIP events on the launch stream (rank-local); the same
+    #      at 16,384 and 65,536 boards
     from tools.microbench import synth_states, time_ms
     B = args.gnn_batch
-    boards = synth_states(B, seed=0, dev=dev)
-    pooled = torch.empty((B, 128), device=dev)
-    policy = torch.empty((B, 209), device=dev)
-    value = torch.empty((B,), device=dev)
     pk = model.packed_weights(dev)
     gnn_flags = model.gnn_flags(dev)          # what GraphPolicyValueNetwork.forward_states passes for this weight set (range guard: proven bound / tracking)
     sat_word = model.saturation_word(dev)
 
-    def fwd():
-        _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(boards), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None,
-                                                      _lib.ptr(value), gnn_flags, _lib.ptr(sat_word), _lib.stream_ptr(dev)), "fwd")
-    # every variant is timed three times in interleaved order and its best time kept: a single pass right after the pools
-    # were freed under-reported the exact-f32 kernel by 3.4x in the round-1 driver run (4.96 M vs 17 M boards/s here)
-    names = (("f32_mfma_exact", 1), ("f16_split_mm_8wave_x2", 6))
-    variants = {n: {"ms_samples": []} for n, _ in names}
+    def forward_fn(nb, flags):
+        bd = synth_states(nb, seed=0, dev=dev)
+        pooled = torch.empty((nb, 128), device=dev)
+        policy = torch.empty((nb, 209), device=dev)
+        value = torch.empty((nb,), device=dev)
+
+        def fwd():
+            _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(bd), 0, nb, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None,
+                                                          _lib.ptr(value), flags, _lib.ptr(sat_word), _lib.stream_ptr(dev)), "fwd")
+        fwd.keep = (bd, pooled, policy, value)
+        return fwd
+    boards = synth_states(B, seed=0, dev=dev)
+    # the builds are timed three times in interleaved order and the best time kept: a single pass right after the pools were freed
+    # under-reported the exact-f32 kernel by 3.4x in the round-1 driver run (its scratch arena grows on first use)
+    builds = {"proven_build": forward_fn(B, _lib.GNN_RANGE_PROVEN), "tracking_build": forward_fn(B, 0), "f32_mfma_exact": forward_fn(B, _lib.GNN_EXACT_F32)}
+    samples = {k: [] for k in builds}
     for rep in range(3):
-        for name, v in names:
-            _lib.set_option("trunk_variant", v)
-            variants[name]["ms_samples"].append(time_ms(fwd, 60, warmup=10))
-    for name in variants:
-        variants[name]["ms"] = min(variants[name]["ms_samples"])
-        variants[name]["boards_per_s"] = B / (variants[name]["ms"] * 1e-3)
-    _lib.set_option("trunk_variant", 3)
-    fwd_ms = min(time_ms(fwd, 200, warmup=20) for _ in range(2))      # default variant, after the clocks have settled on this workload
+        for k, fn in builds.items():
+            samples[k].append(time_ms(fn, 60, warmup=10))
+    build_rate = {k: B / (min(v) * 1e-3) for k, v in samples.items()}
+    fwd = forward_fn(B, gnn_flags)
+    fwd_ms = min(time_ms(fwd, 200, warmup=20) for _ in range(2))      # what this weight set runs, after the clocks have settled on this workload
+    fwd_rates = {str(B): B / (fwd_ms * 1e-3)}
+    for nb in (16384, 65536):
+        if world == 1:
+            f2 = forward_fn(nb, gnn_flags)
+            fwd_rates[str(nb)] = nb / (min(time_ms(f2, 30, warmup=5) for _ in range(2)) * 1e-3)
+            del f2
+    del builds
 
     step_leg = refill_leg = train_leg = legal_leg = graph_leg = None
     if world == 1 and not args.no_extra_legs:
@@ -335,18 +463,14 @@ def main():
             pol_g, _ = model(gx, gei, gb)
             gms = time_ms(lambda: model(gx, gei, gb), 10, warmup=2)
             pol_b, _ = model.forward_states(boards)
-        graph_leg = {"workload": f"forward(x, edge_index, batch) on the {B} boards of gnn_forward as a graph batch ({gx.shape[0]} nodes, {gei.shape[1]} directed edges)",
-                     "boards_per_s": B / (gms * 1e-3), "ms": gms, "max_abs_diff_vs_board_path": float((pol_g - pol_b).abs().max()),
-                     "note": "the generic boundary path: host-side gcn_norm + CSR by torch ops on every call, plain f32 kernels (linear on the "
-                             "vector unit, CSR gather, pool), exact-f32 heads; it takes ANY graph batch. The engine never uses it: boards go "
-                             "through the fused trunk (gnn_forward)"}
+        graph_leg = {"boards": B, "nodes": int(gx.shape[0]), "directed_edges": int(gei.shape[1]), "boards_per_s": B / (gms * 1e-3), "ms": gms,
+                     "max_abs_diff_vs_board_path": float((pol_g - pol_b).abs().max())}
         # (every MultiSetSelfPlay of a process runs on the same four streams, engine._SET_STREAMS: a second engine on four NEW streams
         # would share hardware queues with the first one's idle streams and ran 35 % slower)
         del eng
         torch.cuda.empty_cache()
         # ---- the fused MCTS step kernel alone: one wavefront per game, one dependent chain of loads per tree level
-        step_leg = {"kernel": "engine_step_fast_kernel<9> (backup + expansion of the previous simulation, PUCT descent, legal moves of the leaf)",
-                    "bound": "latency", "us_per_launch": {}, "game_steps_per_s": {}, "waves_per_simd": {}}
+        step_leg = {"kernel": "engine_step_fast_kernel<9>", "bound": "latency", "us_per_launch": {}, "game_steps_per_s": {}}
         for G in (512, 4096):
             # the real loop, one game set alone on the GPU with plain launches, HIP event pairs around the step launches
             # (aqg_set_option("profile_trunk", 2)): plies 24-31 of a GNN-evaluated generation
@@ -366,14 +490,7 @@ def main():
             step_leg["us_per_launch"][str(G)] = us
             step_leg["launches_timed"] = int(n)
             step_leg["game_steps_per_s"][str(G)] = G / (us * 1e-6)
-            step_leg["waves_per_simd"][str(G)] = G / 1024.0
             del e1
-        step_leg["note"] = ("HIP event pairs around every step launch of plies 24-31 of GNN-evaluated games (the pair also brackets the "
-                            "dispatch gap, ~3 us: rocprofv3 on the bench command gives 14.8 us at 512 games, profiles/r03_bench_kernel_stats_default_4sets.csv); one "
-                            "wavefront per game; per simulation ONE round of dependent loads (root record + root children + the previous "
-                            "leaf's policy, everything else patched in registers) plus one per tree level below the root; no bandwidth or "
-                            "FLOP roof applies (PMC: profiles/r03_pmc_summary.csv) -- the figure of merit is us per launch, which the "
-                            "chain step -> trunk -> heads pays once per simulation")
         # ---- slot refill: the same 2048 slots, 3 x 2048 games; a finished game's slot takes the next game
         torch.cuda.empty_cache()
         er = MultiSetSelfPlay(model, num_games=args.games, sims=args.sims, num_sets=args.sets, seed=4242, quota=3 * args.games)
@@ -385,13 +502,9 @@ def main():
         dtr = time.time() - t1
         rpos = int(er.history_tensors()[0].shape[0])
         rplies = max(e2.moves_done for e2 in er.sets)
-        refill_leg = {"workload": f"{3 * args.games} games on {args.games} slots x {args.sims} sims/move, refilled as games end (engine quota)",
-                      "games_per_s": cr["finished"] / dtr, "s": dtr, "games": cr["finished"], "positions": rpos, "plies_played": rplies,
+        refill_leg = {"games": cr["finished"], "slots": args.games, "games_per_s": cr["finished"] / dtr, "s": dtr, "positions": rpos, "plies_played": rplies,
                       "slot_utilisation": rpos / max(1.0, float(args.games) * rplies),
-                      "lockstep_slot_utilisation": positions / max(1.0, float(args.games * world) * last_plies[0]),
-                      "note": "slot_utilisation = positions played / (slots x plies the engine ran). Refill keeps the slots busy but mixes game "
-                              "phases inside every step launch, and a launch lasts as long as its slowest wavefront (an opening position with "
-                              "~130 legal moves); the lock-step generation of the headline value keeps all games in the same phase"}
+                      "lockstep_slot_utilisation": positions / max(1.0, float(args.games * world) * last_plies[0])}
         del er
         torch.cuda.empty_cache()
         # the same comparison where refill is meant to pay: SHORT games of very different lengths (fake evaluator with a strong
@@ -413,8 +526,7 @@ def main():
             return {"games_per_s": fin / d2, "leaf_evals_per_s": ev / d2, "games": fin, "mean_plies": pos / max(fin, 1),
                     "slot_utilisation": pos / max(1.0, float(args.games) * plies)}
         sg_lock, sg_refill = short_games(1, 3), short_games(3, 1)
-        refill_leg["short_games"] = {"workload": f"fake evaluator, forward bias 40, {args.sims} sims/move: 3 x {args.games} games on {args.games} slots",
-                                     "lockstep": sg_lock, "refill": sg_refill,
+        refill_leg["short_games"] = {"lockstep": sg_lock, "refill": sg_refill,
                                      "refill_over_lockstep_games_per_s": sg_refill["games_per_s"] / sg_lock["games_per_s"],
                                      "games_per_leaf_eval_refill_over_lockstep": (sg_refill["games_per_s"] / sg_refill["leaf_evals_per_s"]) /
                                                                                  (sg_lock["games_per_s"] / sg_lock["leaf_evals_per_s"])}
@@ -445,21 +557,12 @@ def main():
         torch.cuda.synchronize()
         train_ms_f32 = (time.time() - t1) / nsteps * 1e3
         _lib.set_option("train_fused", 2)
-        train_leg = {"workload": "train_network.py epoch on the GNN: forward + CE(softmaxed policy) + MSE + backward + Adam, f32 data, batch 128, "
-                                 f"{nsteps} steps in one aqg_gcn_train_steps call (shuffle applied once per epoch)",
-                     "ms_per_step": train_ms, "positions_per_s": BATCH_SIZE / (train_ms * 1e-3), "ms_per_step_single_calls": step_ms,
-                     "ms_per_step_f32_input_mfma_form": train_ms_f32, "positions_redone_in_f32": fallbacks,
+        train_leg = {"batch": BATCH_SIZE, "steps_per_call": nsteps, "ms_per_step": train_ms, "positions_per_s": BATCH_SIZE / (train_ms * 1e-3),
+                     "ms_per_step_single_calls": step_ms, "ms_per_step_f32_input_mfma_form": train_ms_f32, "positions_redone_in_f32": fallbacks,
                      "launches_per_step": 2,
-                     "roofline": {"kernel": "train_board_split_kernel (one workgroup per position: forward + heads + backward, every contraction "
-                                            "on v_mfma_f32_16x16x32_f16 in hi/lo split precision) + train_final_kernel", "bound": "mfma", "achieved": tflops,
+                     "roofline": {"kernel": "train_board_split_kernel + train_final_kernel", "bound": "mfma", "achieved": tflops,
                                   "peak": PEAK_F16_MFMA / 3 / 1e12, "unit": "TFLOP/s", "frac": tflops * 1e12 / (PEAK_F16_MFMA / 3),
-                                  "frac_vs_f32_input_mfma_peak": tflops * 1e12 / PEAK_F32_MFMA,
-                                  "flop_per_position": TRAIN_FLOP_PER_POSITION,
-                                  "note": "2.2 GFLOP per step (algorithmic f32 FLOP; three fp16 products per f32 product on the pipe); one 8-wave "
-                                          "workgroup per position keeps every activation on its CU, so batch 128 occupies 128 of the 256 CUs and the "
-                                          "step is one position's dependent chain: ~720 MFMAs per wave (23 k of the ~105 k cycles of the kernel at two "
-                                          "waves per SIMD), the heads, 14 barriers (in-kernel stamps: profiles/r03_train_step_phase_stamps.log) -- "
-                                          "latency, not the matrix pipe, bounds it"}}
+                                  "frac_vs_f32_input_mfma_peak": tflops * 1e12 / PEAK_F32_MFMA, "flop_per_position": TRAIN_FLOP_PER_POSITION}}
         del trainer, tr_model
 
     large = None
@@ -474,12 +577,18 @@ def main():
         c, _ = one_step(False)
         torch.cuda.synchronize()
         dt = time.time() - t1
-        large = {"workload": f"one generation, {args.large_games} concurrent games x {args.sims} sims/move, 1 GPU (single timed generation after two untimed warm-up moves)",
-                 "games_per_s": c["finished"] / dt, "s_per_generation": dt, "leaf_evals_per_s": c["leaf_evals"] / dt}
+        large = {"concurrent_games": args.large_games, "sims_per_move": args.sims, "games_per_s": c["finished"] / dt, "s_per_generation": dt,
+                 "leaf_evals_per_s": c["leaf_evals"] / dt}
 
     if rank == 0:
         achieved = trunk_boards * TRUNK_FLOP_PER_BOARD / (trunk_ms * 1e-3) if trunk_ms > 0 else 0.0   # rank 0's sampled launches
         boards_per_s_kernel = trunk_boards / (trunk_ms * 1e-3) if trunk_ms > 0 else 0.0
+        pmc = None                               # matrix-pipe busy share: a RECORDED rocprofv3 --pmc measurement (separate passes), read from
+        pmc_path = os.path.join(ROOT, "profiles", "r04_pmc_trunk.json")      # the file the profiling recipe wrote, never typed in here
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = dict(json.load(f), source="profiles/r04_pmc_trunk.json")
+        fwd_rate = fwd_rates[str(B)]
         out = {
             "metric": "self-play games/sec, 9x9 Quoridor (PV-MCTS, GNN evaluator), whole job",
             "value": total_games / elapsed,
@@ -493,55 +602,37 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 (f16x3-split MFMA products, f32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]/[3]: one self-play generation per step -- concurrent 9x9 games per GPU "
-                                   "played to termination, lock-step PV-MCTS, random-weight GNN evaluator, then the all-gather of (s,pi,z)",
+            "notes_ref": "bench.py docstring + DESIGN.md section 5",
+            "config": {"workload": "BASELINE configs[2]/[3]: one self-play generation per step (lock-step PV-MCTS, random-weight GNN) + all-gather of (s,pi,z)",
                        "games_per_gpu": args.games, "game_sets_per_gpu": args.sets, "sims_per_move": args.sims, "board": "9x9", "walls": 10, "plies_for_draw": 116,
                        "temperature": 1.0, "c_puct": 1.25, "parallelism": f"games sharded over {world} rank(s), 1 all-gather per generation"},
             "leaf_evals_per_s": total_evals / elapsed,
-            "sims_per_s": total_evals / elapsed,   # terminal simulations excluded
             "mean_plies_per_game": mean_plies,
             "positions_gathered_per_step": positions,
-            "gnn_forward": {"workload": f"BASELINE configs[1]: pv_network_gnn forward, batch={B} synthetic boards (trunk + heads)",
-                            "fp16_range_guard": ("static bound over all inputs holds for this weight set: no per-value tracking (AQG_GNN_RANGE_PROVEN)"
-                                                 if gnn_flags & _lib.GNN_RANGE_PROVEN else "per-value range tracking in the epilogues"),
+            "gnn_forward": {"workload": "BASELINE configs[1]: pv_network_gnn forward (trunk + heads), synthetic boards", "batch": B,
+                            "fp16_range_guard": "proven" if gnn_flags & _lib.GNN_RANGE_PROVEN else ("exact_f32" if gnn_flags & _lib.GNN_EXACT_F32 else "tracking"),
                             "range_guard_word_after_run": int(sat_word.item()),
-                            "boards_per_s": B / (fwd_ms * 1e-3), "ms": fwd_ms, "trunk_variants": variants,
-                            "mfma_frac": B / (fwd_ms * 1e-3) * FWD_FLOP_PER_BOARD / (PEAK_F16_MFMA / SPLIT_TERMS),
-                            "frac_vs_f32_input_mfma_peak": B / (fwd_ms * 1e-3) * FWD_FLOP_PER_BOARD / PEAK_F32_MFMA,
-                            "hbm_frac_survey_formula": B / (fwd_ms * 1e-3) * HBM_BYTES_PER_BOARD / PEAK_HBM},
-            "roofline": {"kernel": "gcn_trunk_boards_mm_kernel<1,2,false,TRACK> (GCN trunk: linear maps + aggregation on fp16 split MFMA; TRACK = false when the weight set's fp16 range is proven by a static bound, as for this run's weights)", "bound": "mfma",
+                            "boards_per_s": fwd_rate, "ms": fwd_ms, "boards_per_s_by_batch": fwd_rates, "boards_per_s_by_build": build_rate,
+                            "mfma_frac": fwd_rate * FWD_FLOP_PER_BOARD / (PEAK_F16_MFMA / SPLIT_TERMS),
+                            "frac_vs_f32_input_mfma_peak": fwd_rate * FWD_FLOP_PER_BOARD / PEAK_F32_MFMA,
+                            "hbm_frac_survey_formula": fwd_rate * HBM_BYTES_PER_BOARD / PEAK_HBM},
+            "roofline": {"kernel": "gcn_trunk_boards_mm_kernel<TRACK> (TRACK 0: fp16 range proven for this weight set)", "bound": "mfma",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / SPLIT_TERMS / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / (PEAK_F16_MFMA / SPLIT_TERMS),
                          "traffic": None,
-                         "traffic_note": "HBM is not a roof of this kernel: activations never leave LDS, the weight fragments come from L2; compulsory "
-                                         f"traffic is {TRUNK_COMPULSORY_BYTES_PER_BOARD} B/board (record in + pooled row out) = "
-                                         f"{boards_per_s_kernel * TRUNK_COMPULSORY_BYTES_PER_BOARD / PEAK_HBM * 100:.2f} % of 8 TB/s at this rate; "
-                                         "PMC-measured bytes of this round: profiles/r03_pmc_summary.csv (collected by a separate rocprofv3 pass, "
-                                         "quoted in DESIGN.md section 5); the algorithmic layer-granular figure is 169,760 B/board (hbm_frac_survey_formula)",
+                         "compulsory_bytes_per_board": TRUNK_COMPULSORY_BYTES_PER_BOARD,
+                         "compulsory_hbm_frac": boards_per_s_kernel * TRUNK_COMPULSORY_BYTES_PER_BOARD / PEAK_HBM,
                          "frac_vs_dense_f16_peak": achieved / PEAK_F16_MFMA,
-                         "mfma_busy_pmc": {"boards_per_launch_65536": 0.52, "boards_per_launch_480": 0.31,
-                                           "source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) from the separate rocprofv3 --pmc passes of "
-                                                     "this round, profiles/r03_pmc_summary.csv (480: busy cycles against the un-instrumented 12.99 us launch x 2.4 GHz x 1024 SIMDs; "
-                                                     "0.20 against the counter pass's own, instrumented, GRBM_GUI_ACTIVE); a recorded "
-                                                     "measurement, not taken in this run"},
+                         "mfma_busy_pmc": pmc,
                          "launches": trunk_launches, "avg_launch_us": trunk_ms / max(trunk_launches, 1) * 1e3,
                          "boards_per_launch_avg": trunk_boards / max(trunk_launches, 1),
-                         "launches_sampled": "every trunk launch of one game set's move on plies 27/83 of each timed generation; that set runs alone on the GPU with plain launches for that move, all other moves replay captured hipGraphs with the sets overlapping",
                          "flop_per_board": TRUNK_FLOP_PER_BOARD,
                          "hbm_frac_survey_formula": boards_per_s_kernel * HBM_BYTES_PER_BOARD / PEAK_HBM,
                          "frac_vs_f32_input_mfma_peak": achieved / PEAK_F32_MFMA,
-                         "f16_mfma_issued_tflops": boards_per_s_kernel * TRUNK_MFMA_PER_BOARD * 16384 / 1e12, "f16_mfma_peak_tflops": PEAK_F16_MFMA / 1e12,
-                         "note": "default trunk = all-MFMA fp16 split (f32 data, f32 accumulate, 3 fp16 products hi*hi+hi*lo+lo*hi per f32 "
-                                 "product; the GCN aggregation is a banded 0/1 adjacency MFMA: fp32-equivalent, same 1e-5/1e-4 tolerance as "
-                                 "the exact f32-input MFMA variant). "
-                                 "achieved = ALGORITHMIC f32 FLOP/s (5,432,832 per board x boards / kernel time from HIP events around "
-                                 "every launch); peak = dense fp16 MFMA peak / 3 split terms = the matrix-pipe roof of this algorithm "
-                                 "(the exact f32-input MFMA roof of SURVEY 8d is 157.3 TFLOP/s: frac_vs_f32_input_mfma_peak; against the plain dense "
-                                 "fp16 peak of 2.5 PFLOP/s: frac_vs_dense_f16_peak). Launches inside the MCTS carry one game set's leaves, ~480 "
-                                 "boards = one board per workgroup (512 workgroups, two per CU), so avg_launch_us is one board's latency chain "
-                                 "plus the launch overhead; gnn_forward.trunk_variants is the same kernel at 4,096 boards per launch. Matrix-pipe "
-                                 "busy share (SQ_VALU_MFMA_BUSY_CYCLES) from the PMC passes of this round: profiles/r03_pmc_summary.csv"},
+                         "f16_mfma_issued_tflops": boards_per_s_kernel * TRUNK_MFMA_PER_BOARD * 16384 / 1e12},
         }
+        if rccl_leg is not None:
+            out["rccl_group_alive"] = rccl_leg
         legal_sample = legal_leg.pop("_sample", None) if legal_leg is not None else None
         if legal_leg is not None:
             out["legal_mask"] = legal_leg
@@ -560,8 +651,15 @@ def main():
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
             if legal_sample is not None:
                 out["cpu_baseline"]["legal_mask_states_per_s_per_core"] = cpu_legal_baseline(legal_sample)
-                out["cpu_baseline"]["legal_mask_sample"] = "oracle C rules (the reference's algorithm) on 4,096 of the legal_mask leg's states, one core"
-        print(json.dumps(out))
+        def _round(x):                     # six significant digits: the line stays well under the 8 KB tail a driver keeps
+            if isinstance(x, float):
+                return float(f"{x:.6g}")
+            if isinstance(x, dict):
+                return {k: _round(v) for k, v in x.items()}
+            if isinstance(x, (list, tuple)):
+                return [_round(v) for v in x]
+            return x
+        print(json.dumps(_round(out), separators=(",", ":")))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
