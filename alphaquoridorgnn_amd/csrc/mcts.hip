@@ -26,6 +26,8 @@
 
 namespace aqg {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 int launch_legal_actions(int N, const void* states, int fmt, int B, uint8_t* mask, uint8_t* order, int32_t* count,
                          const uint8_t* active, hipStream_t st);
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
@@ -109,13 +111,15 @@ __device__ __forceinline__ QState uniform_state(const QState& v) {
 
 // One reference-"Node" (pv_mcts.py:24-31) per 32-byte record: the statistics, the prior, the action that led here and
 // the child range sit in one cache sector, so a descent level is ONE dependent load round (the chosen child's
-// `kids` and `action` arrive together with its w/n/p).
+// `kids` and `action` arrive together with its w/n/p) of two aligned 16-byte loads per child.
 struct alignas(32) NodeRec {
+    // cold half (bytes 0..15): what a descent needs only of the child it CHOSE
     double w;          // cumulative value (python float in the reference)
     float p;           // prior
+    uint32_t action;   // action that led to this node (0xFF for the root)
+    // hot half (bytes 16..31): what PUCT scores every child with -- one aligned 16-byte load per child
     int32_t n;         // visit count
     uint32_t kids;     // first child (24 bits) | child count << 24 ; 0 = unexpanded
-    uint32_t action;   // action that led to this node (0xFF for the root)
     float q;           // f32(-w / n) as PUCT adds it (pv_mcts.py:74), 0 while n == 0: maintained by every writer of (w, n), so the
                        // descent reads it with the record instead of doing a float64 division per tree level on its critical path
     float cp;          // f32(C_PUCT * p), the first product of PUCT's exploration term (pv_mcts.py:75, evaluated left to right in f32):
@@ -494,9 +498,15 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
         }
     }
     const NodeRec rootrec = nodes[0];
-    NodeRec rc[3];
+    // (children travel as the record's two aligned 16-byte halves -- [2 i] = {w.lo, w.hi, p, action}, [2 i + 1] = {n, kids, q, cp} -- and
+    //  stay vectors: as separate scalars their loop-carried copies were made behind an s_waitcnt at the descent loop's back edge)
+    const u32x4* __restrict__ nhalf = reinterpret_cast<const u32x4*>(nodes);
+    u32x4 hot[3], cold[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) rc[r] = nodes[min(1 + lane + 64 * r, e.node_cap - 1)];
+    for (int r = 0; r < 3; ++r) {
+        const int i = min(1 + lane + 64 * r, e.node_cap - 1);
+        cold[r] = nhalf[2 * i]; hot[r] = nhalf[2 * i + 1];
+    }
     if (!do_expand) flag = 0;
     // (wave-uniform values the compiler cannot know to be uniform: as scalars they steer branches and v_readlane)
     flag = __builtin_amdgcn_readfirstlane(flag); depth_old = __builtin_amdgcn_readfirstlane(depth_old);
@@ -614,10 +624,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     int mynode = 0;                   // lane d: new path node at depth d ...
     double nw = 0.0; int nn = 0;      // ... and its current (w, n), pending updates included
     const bool pend0 = flag == 1 && fast_old;                        // (wave-uniform) the old path's backup is pending in registers
-    if (lane == 0) {
-        path[0] = 0;
-        if (regs) { nw = pend0 ? bw : rootrec.w; nn = pend0 ? bn : rootrec.n; }
-    }
+    if (lane == 0 && regs) { nw = pend0 ? bw : rootrec.w; nn = pend0 ? bn : rootrec.n; }
     bool onpath = pend0;              // the current node IS the old path's node at this depth
     int terminal = 0;
     double tvalue = 0.0;
@@ -625,113 +632,155 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     kids = (uint32_t)__builtin_amdgcn_readfirstlane((int)kids);
     // n of the current node with the pending backup applied (lane 0 holds the root's)
     int npar = __builtin_amdgcn_readfirstlane(regs ? (pend0 ? bn : rootrec.n) : nodes[0].n);
-    // children of the current node, fetched one level ahead of their use: the root's come from round 1, everything else is one
-    // dependent load round per level.  All three slots are requested whatever the child count (lanes / slots beyond it read the
-    // last child, or node 0 for an unexpanded child: same cache lines, and no conditional assignment for the compiler to merge with
-    // copies behind an s_waitcnt at the loop's back edge).  The records are never modified in registers: the pending backup's
-    // patch goes into temporaries.
-    NodeRec rec[3];
-    auto fetch_children = [&](uint32_t k) {
-        const int cnt = (int)(k >> 24), first = (int)(k & 0xFFFFFF);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) rec[r] = nodes[first + max(min(lane + 64 * r, cnt - 1), 0)];
-    };
-    if (regs) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) rec[r] = rc[r];
-    } else fetch_children(kids);
-    bool at_old_leaf = false;
-    for (;;) {
-        const bool lose = is_lose<N>(s), draw = is_draw(s, e.plies_for_draw);
-        if (lose || draw) { tvalue = lose ? -1.0 : 0.0; terminal = 1; break; }      // pv_mcts.py:35-42
+    // One level's selection (pv_mcts.py:69-78) from the children's records `hot` / `cold`; results in the scalars below.  The records
+    // are never modified in registers: the pending backup's patch goes into temporaries.
+    uint32_t kids_n = 0u; int action = 0, cn = 0, besti = 0; double cw = 0.0;
+    auto select_level = [&](const u32x4 (&hot)[3], const u32x4 (&cold)[3]) {
         const int cnt = (int)(kids >> 24), first = (int)(kids & 0xFFFFFF);
-        if (cnt == 0) break;                                                         // pv_mcts.py:45 unexpanded leaf
-        // The current node is the old leaf, expanded a moment ago: handled behind the loop (no record is needed there)
-        if (regs && onpath && depth == depth_old) { at_old_leaf = true; break; }
-        uint32_t kids_n; int action, cn, besti; double cw;
-        {
-            // the old path's child of this node: its index among these children, and its exploitation term after the pending backup --
-            // lane depth + 1 computed it from that node's own record (one division per step, started before the descent); at the root
-            // it is formed below from the round-1 copy, so that level 0 does not wait for the second load round
-            const bool patch = regs && onpath && depth < depth_old;
-            const int pidx = patch ? __builtin_amdgcn_readlane(pnode, (depth + 1) & 63) - first : -1;
-            const float pq = (patch && depth > 0) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bq), (depth + 1) & 63)) : 0.f;
-            const float st = sqrtf((float)(npar - 1));            // == f32(math.sqrt(t)), see game_select; t = npar - 1
-            float sc[3] = {-INFINITY, -INFINITY, -INFINITY};
-            int neff[3] = {rec[0].n, rec[1].n, rec[2].n};
-            uint32_t keff[3] = {rec[0].kids, rec[1].kids, rec[2].kids};
+        // the old path's child of this node: its index among these children, and its exploitation term after the pending backup --
+        // lane depth + 1 computed it from that node's own record (one division per step, started before the descent); at the root
+        // it is formed below from the round-1 copy, so that level 0 does not wait for the second load round
+        const bool patch = regs && onpath && depth < depth_old;
+        const int pidx = patch ? __builtin_amdgcn_readlane(pnode, (depth + 1) & 63) - first : -1;
+        const float pq = (patch && depth > 0) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bq), (depth + 1) & 63)) : 0.f;
+        const float st = sqrtf((float)(npar - 1));                // == f32(math.sqrt(t)), see game_select; t = npar - 1
+        // At the root the patched child's q cannot come from lane 1 (that lane's record is the second load round): it is formed from
+        // the round-1 copy of the child itself -- one float64 division per step, under a scalar branch, in front of the scores
+        float q0fix = 0.f;
+        if (patch && depth == 0) {
+            const int ps = pidx >> 6;
+            const u32x4 cc = ps == 0 ? cold[0] : (ps == 1 ? cold[1] : cold[2]);
+            const u32x4 hh = ps == 0 ? hot[0] : (ps == 1 ? hot[1] : hot[2]);
+            const uint32_t w0 = cc[0], w1 = cc[1], nb = hh[0];
+            const double wr = __builtin_bit_cast(double, ((uint64_t)w1 << 32) | w0);
+            q0fix = q_of(wr + (((depth_old - 1) & 1) ? -v_old : v_old), (int)nb + 1);   // (only the lane of the patched child uses it)
+        }
+        const float pqv = depth == 0 ? q0fix : pq;
+        const bool leafnext = patch && depth + 1 == depth_old;     // the patched child is the old leaf: it has children now
+        float sc[3];
+        int neff[3];
+        uint32_t keff[3];
+        // straight-line scores: the slots' chains (patch by selects, int -> float, multiply, IEEE division, add) are independent, so
+        // that the in-order issue of a lone wave interleaves them; nodes with at most 64 children (every node once the walls are
+        // placed) take the one-slot copy of the same code
+        auto score = [&](int r) {
+            // (elements go through scalars: __builtin_bit_cast of a vector ELEMENT expression reads element 0 with hipcc 7.2)
+            const uint32_t nb = hot[r][0], kb = hot[r][1], qb = hot[r][2], cb = hot[r][3];
+            const bool me = patch && (lane + 64 * r == pidx);
+            neff[r] = (int)nb + (me ? 1 : 0);
+            keff[r] = (me && leafnext) ? kids_new : kb;
+            const float q = me ? pqv : __builtin_bit_cast(float, qb);          // q = f32(-w / n) travels with the record (NodeRec::q)
+            const float u = (__builtin_bit_cast(float, cb) * st) / (float)(1 + neff[r]);
+            sc[r] = (lane + 64 * r < cnt) ? q + u : -INFINITY;
+        };
+        if (cnt <= 64) {
+            score(0);
+            sc[1] = sc[2] = -INFINITY; neff[1] = neff[2] = 0; keff[1] = keff[2] = 0u;
+        } else {
+            score(0); score(1); score(2);
+        }
+        // np.argmax: the first index of the maximum.  Wave maximum by DPP, then the lowest child index holding it from up to three
+        // ballots (children lane, lane + 64, lane + 128 in that order), masked to the node's children.  NaN scores never equal the
+        // maximum; if nothing matches (all NaN) child 0 is taken, as before.
+        const float best = wave_max_dpp_asm(fmaxf(fmaxf(sc[0], sc[1]), sc[2]));
+        const uint64_t v0 = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+        const uint64_t m0 = __ballot(sc[0] == best) & v0;
+        int bi = 0;
+        if (m0) bi = __builtin_ctzll(m0);
+        else if (cnt > 64) {
+            const uint64_t v1 = cnt >= 128 ? ~0ull : ((1ull << (cnt - 64)) - 1ull);
+            const uint64_t m1 = __ballot(sc[1] == best) & v1;
+            if (m1) bi = 64 + __builtin_ctzll(m1);
+            else if (cnt > 128) {
+                const uint64_t m2 = __ballot(sc[2] == best) & ((1ull << (cnt - 128)) - 1ull);
+                if (m2) bi = 128 + __builtin_ctzll(m2);
+            }
+        }
+        besti = __builtin_amdgcn_readfirstlane(bi);
+        const int slot = besti >> 6, src = besti & 63;          // wave-uniform: the winner's fields come by v_readlane
+        uint32_t wlo, whi;
+        auto pick = [&](const u32x4 c, uint32_t k, int n) {
+            const uint32_t c0 = c[0], c1 = c[1], c3 = c[3];
+            kids_n = (uint32_t)__builtin_amdgcn_readlane((int)k, src);
+            action = __builtin_amdgcn_readlane((int)c3, src);
+            cn = __builtin_amdgcn_readlane(n, src);
+            wlo = (uint32_t)__builtin_amdgcn_readlane((int)c0, src);
+            whi = (uint32_t)__builtin_amdgcn_readlane((int)c1, src);
+        };
+        if (slot == 0) pick(cold[0], keff[0], neff[0]); else if (slot == 1) pick(cold[1], keff[1], neff[1]); else pick(cold[2], keff[2], neff[2]);
+        cw = __builtin_bit_cast(double, ((uint64_t)whi << 32) | wlo);   // (used only if the path ends on a terminal node off the old path)
+        node = first + besti;
+        onpath = patch && besti == pidx;                        // the new path follows the old one a level further
+        // (every element of the six vectors stays allocated up to here: the record's p is never read, and the allocator handed the
+        //  register of that dead element of an IN-FLIGHT load to the next temporary -- a write-after-write hazard it then covered with an
+        //  s_waitcnt vmcnt(0) right behind the request)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) asm volatile("" :: "v"(hot[r]), "v"(cold[r]));
+    };
+    // what stops the descent at the current node: 1 terminal, 2 unexpanded leaf, 3 the old leaf (expanded a moment ago: its children are
+    // the records built above -- handled behind the loop, no record is needed there), 0 go on
+    auto stop_here = [&]() -> int {
+        const bool lose = is_lose<N>(s), draw = is_draw(s, e.plies_for_draw);
+        if (lose || draw) { tvalue = lose ? -1.0 : 0.0; terminal = 1; return 1; }   // pv_mcts.py:35-42
+        if ((kids >> 24) == 0) return 2;                                            // pv_mcts.py:45 unexpanded leaf
+        if (regs && onpath && depth == depth_old) return 3;
+        return 0;
+    };
+    // Children travel as the record's two aligned 16-byte halves and are requested for all three slots whatever the child count (lanes /
+    // slots beyond it read the last child, or node 0 for an unexpanded child: same cache lines, no divergent region around the loads).
+    // They are loaded and consumed inside ONE loop iteration -- a loop-carried record cost a copy of every register behind an
+    // s_waitcnt at the back edge -- and what the previous level's choice still owes (next() of the game state, the path, the chosen
+    // child's statistics for its lane) is done between the request and the first use: behind the loads, off the level's chain.
+    bool at_old_leaf = false;
+    int stop = stop_here();
+    if (stop == 0) {
+        if (!regs) {                      // (deep old path, written through memory above: the round-1 copies are stale)
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                if (64 * r < cnt) {                                // (scalar branch: most nodes below the root have < 64 children)
-                    float q = rec[r].q;                            // q = f32(-w / n) travels with the record (NodeRec::q)
-                    if (patch && (pidx >> 6) == r) {               // (scalar branch) this slot holds the old path's child
-                        const bool me = lane == (pidx & 63);
-                        if (depth == 0) {
-                            if (me) q = q_of(rec[r].w + (((depth_old - 1) & 1) ? -v_old : v_old), rec[r].n + 1);
-                        } else q = me ? pq : q;
-                        neff[r] += me ? 1 : 0;
-                        if (depth + 1 == depth_old) keff[r] = me ? kids_new : keff[r];
-                    }
-                    const float u = (rec[r].cp * st) / (float)(1 + neff[r]);
-                    sc[r] = (lane + 64 * r < cnt) ? q + u : -INFINITY;
+                const int i = (int)(kids & 0xFFFFFF) + max(min(lane + 64 * r, (int)(kids >> 24) - 1), 0);
+                cold[r] = nhalf[2 * i]; hot[r] = nhalf[2 * i + 1];
+            }
+        }
+        select_level(hot, cold);          // level 0: the root's children came with round 1
+        for (;;) {
+            // next level's children (hand-over to memory first: flush what is pending, fence, go on reading memory)
+            if (regs && depth + 1 >= fast_depth) {
+                flush_old();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                regs = false;
+                onpath = false;
+            }
+            // (Requesting the old path's next child block speculatively, before the scores are computed, was tried: the level
+            //  got 14 % SLOWER -- a wrong guess costs a second round.)
+            u32x4 h[3], c[3];
+            {
+                const int cnt = (int)(kids_n >> 24), first = (int)(kids_n & 0xFFFFFF);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int i = first + max(min(lane + 64 * r, cnt - 1), 0);
+                    c[r] = nhalf[2 * i]; h[r] = nhalf[2 * i + 1];
                 }
             }
-            // np.argmax: the first index of the maximum.  Wave maximum by DPP, then the lowest child index holding it from up to three
-            // ballots (children lane, lane + 64, lane + 128 in that order), masked to the node's children.  NaN scores never equal the
-            // maximum; if nothing matches (all NaN) child 0 is taken, as before.
-            const float best = wave_max_dpp_asm(fmaxf(fmaxf(sc[0], sc[1]), sc[2]));
-            const uint64_t v0 = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
-            const uint64_t m0 = __ballot(sc[0] == best) & v0;
-            besti = 0;
-            if (m0) besti = __builtin_ctzll(m0);
-            else if (cnt > 64) {
-                const uint64_t v1 = cnt >= 128 ? ~0ull : ((1ull << (cnt - 64)) - 1ull);
-                const uint64_t m1 = __ballot(sc[1] == best) & v1;
-                if (m1) besti = 64 + __builtin_ctzll(m1);
-                else if (cnt > 128) {
-                    const uint64_t m2 = __ballot(sc[2] == best) & ((1ull << (cnt - 128)) - 1ull);
-                    if (m2) besti = 128 + __builtin_ctzll(m2);
-                }
-            }
-            besti = __builtin_amdgcn_readfirstlane(besti);
-            const int slot = besti >> 6, src = besti & 63;      // wave-uniform: the winner's fields come by v_readlane
-            uint32_t wlo, whi;
-            auto pick = [&](const NodeRec& c, uint32_t k, int n) {
-                kids_n = (uint32_t)__builtin_amdgcn_readlane((int)k, src);
-                action = __builtin_amdgcn_readlane((int)c.action, src);
-                cn = __builtin_amdgcn_readlane(n, src);
-                const uint64_t wbits = __builtin_bit_cast(uint64_t, c.w);
-                wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wbits, src);
-                whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wbits >> 32), src);
-            };
-            if (slot == 0) pick(rec[0], keff[0], neff[0]); else if (slot == 1) pick(rec[1], keff[1], neff[1]); else pick(rec[2], keff[2], neff[2]);
-            cw = __builtin_bit_cast(double, ((uint64_t)whi << 32) | wlo);   // (used only if the path ends on a terminal node off the old path)
-            onpath = patch && besti == pidx;                    // the new path follows the old one a level further
-        }
-        node = first + besti;
-        ++depth;
-        // next level's children
-        if (regs && depth >= fast_depth) {          // hand over to memory: flush what is pending, fence, go on reading memory
-            flush_old();
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            regs = false;
-        }
-        kids = kids_n;
-        npar = cn;
-        // (Requesting the old path's next child block speculatively, before the scores are computed, was tried: the level
-        //  got 14 % SLOWER -- a wrong guess costs a second round.)
-        fetch_children(kids);
-        // ... and behind the loads: the game state, the path, the chosen child's statistics for lane `depth`
-        s = next_state<N>(s, action);
-        if (lane == 0) path[depth] = node;
-        const bool stay = regs && onpath;
-        if (lane == (depth & 63) && depth < 64) { mynode = node; nw = stay ? bw : cw; nn = stay ? bn : cn; }
+            // ... and behind the loads: the chosen child becomes the current node
+            ++depth;
+            kids = kids_n;
+            npar = cn;
+            s = next_state<N>(s, action);
+            // (the path stays in registers -- lane d owns depth d -- and is written once behind the descent: a store per level sat in
+            //  the same in-order counter as the next level's loads.  Depths beyond 63, never seen, go through memory at once.)
+            if (depth >= 64 && lane == 0) path[depth] = node;
+            if (lane == (depth & 63) && depth < 64) { mynode = node; nw = onpath ? bw : cw; nn = onpath ? bn : cn; }
 #ifdef AQG_STAMP
-        if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[6] += 1;     // levels descended
+            if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[6] += 1;     // levels descended
 #endif
+            stop = stop_here();
+            if (stop) break;
+            select_level(h, c);
+        }
     }
+    at_old_leaf = stop == 3;
     if (at_old_leaf) {
         // The descent has followed the old path down to the old leaf, whose children are the records built above (n = 0, q = 0).  Their
         // visit counts sum to t = 0, so every score is 0 + (cp * 0) / 1 = 0 (or NaN for a NaN prior: never the maximum) and np.argmax
@@ -740,7 +789,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
         node = (int)(kids & 0xFFFFFF);
         s = next_state<N>(s, __builtin_amdgcn_readlane((int)oa[0], 0));
         ++depth;
-        if (lane == 0) path[depth] = node;
+        if (depth >= 64 && lane == 0) path[depth] = node;
         if (lane == (depth & 63) && depth < 64) { mynode = node; nw = 0.0; nn = 0; }
         const bool lose = is_lose<N>(s), draw = is_draw(s, e.plies_for_draw);
         if (lose || draw) { tvalue = lose ? -1.0 : 0.0; terminal = 1; }
@@ -748,6 +797,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
         if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[6] += 1;
 #endif
     }
+    if (lane <= min(depth, 63)) path[lane] = mynode;             // the new path, depths 0..63 (lane 0: the root, node 0)
 #ifdef AQG_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

@@ -619,16 +619,16 @@ def test_predict_contract(dev):
 
 def _root_children(eng):
     """Root children of every game after a search, straight from the tree pool (csrc/mcts.hip NodeRec, 32 bytes:
-    f64 w | f32 p | i32 n | u32 first_child + (count << 24) | u32 action | pad): (priors, visits, actions) per game."""
+    f64 w | f32 p | u32 action || i32 n | u32 first_child + (count << 24) | f32 q | f32 C_PUCT * p): (priors, visits, actions) per game."""
     G, cap = eng.G, eng.node_cap
     raw = eng.t["node_rec"].view(torch.uint8).view(G, cap, 32).cpu().numpy()
     out = []
     for g in range(G):
-        kids = int(raw[g, 0, 16:20].view(np.uint32)[0])
+        kids = int(raw[g, 0, 20:24].view(np.uint32)[0])
         first, cnt = kids & 0xFFFFFF, kids >> 24
         ch = raw[g, first:first + cnt]
-        out.append((ch[:, 8:12].copy().view(np.float32)[:, 0], ch[:, 12:16].copy().view(np.int32)[:, 0],
-                    ch[:, 20:24].copy().view(np.uint32)[:, 0]))
+        out.append((ch[:, 8:12].copy().view(np.float32)[:, 0], ch[:, 16:20].copy().view(np.int32)[:, 0],
+                    ch[:, 12:16].copy().view(np.uint32)[:, 0]))
     return out
 
 

@@ -25,7 +25,7 @@ for sv in (0, 1):
     epol = eng.t["policy"].cpu().numpy()
     for i, rec in enumerate(recs):
         st = oq.State(rec); legal = st.legal_actions()
-        kids = int(raw[i, 0, 16:20].view(np.uint32)[0]); first, cnt = kids & 0xFFFFFF, kids >> 24
+        kids = int(raw[i, 0, 20:24].view(np.uint32)[0]); first, cnt = kids & 0xFFFFFF, kids >> 24
         pri = raw[i, first:first + cnt, 8:12].copy().view(np.float32)[:, 0]
         want, _ = oracle.predict(st)
         fwd = pol[i][legal]; fwd = fwd / fwd.sum()
