@@ -32,11 +32,12 @@ int launch_legal_actions(int N, const void* states, int fmt, int B, uint8_t* mas
                          const uint8_t* active, hipStream_t st);
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
-                              int flags, int32_t* saturated, hipStream_t st);
+                              int flags, int32_t* saturated, unsigned int* group_sync, hipStream_t st);
 size_t boards_any_workspace_floats(int N, int B);
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
-                                  float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st);
+                                  float* value, const uint8_t* active, int flags, int32_t* saturated, unsigned int* group_sync, hipStream_t st);
+extern int g_heads_in_trunk;
 extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, g_profile_trunk, g_trunk_prio, g_heads_prio;
 void profile_mark(hipStream_t st, long long units);
 int g_use_graph = 1;       // aqg_set_option("use_graph", 0) forces plain launches
@@ -458,6 +459,7 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
 #ifdef AQG_STAMP
 #define STEP_STAMP_DECL unsigned long long sp_prev = __builtin_readcyclecounter();
 #define STEP_STAMP(i) { const unsigned long long sp_now = __builtin_readcyclecounter(); if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[i] += sp_now - sp_prev; sp_prev = sp_now; }
+#define LEVEL_STAMP(i) { const unsigned long long lv_now = __builtin_readcyclecounter(); if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[i] += lv_now - lv_prev; lv_prev = lv_now; }
 #else
 #define STEP_STAMP_DECL
 #define STEP_STAMP(i)
@@ -732,6 +734,9 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     // s_waitcnt at the back edge -- and what the previous level's choice still owes (next() of the game state, the path, the chosen
     // child's statistics for its lane) is done between the request and the first use: behind the loads, off the level's chain.
     bool at_old_leaf = false;
+#ifdef AQG_STAMP
+    unsigned long long lv_prev = __builtin_readcyclecounter();
+#endif
     int stop = stop_here();
     if (stop == 0) {
         if (!regs) {                      // (deep old path, written through memory above: the round-1 copies are stale)
@@ -742,6 +747,9 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
             }
         }
         select_level(hot, cold);          // level 0: the root's children came with round 1
+#ifdef AQG_STAMP
+        lv_prev = __builtin_readcyclecounter();
+#endif
         for (;;) {
             // next level's children (hand-over to memory first: flush what is pending, fence, go on reading memory)
             if (regs && depth + 1 >= fast_depth) {
@@ -755,6 +763,9 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
             // (Requesting the old path's next child block speculatively, before the scores are computed, was tried: the level
             //  got 14 % SLOWER -- a wrong guess costs a second round.)
             u32x4 h[3], c[3];
+#ifdef AQG_STAMP
+            LEVEL_STAMP(11)                                  // child chosen -> next request (hand-over test, addresses)
+#endif
             {
                 const int cnt = (int)(kids_n >> 24), first = (int)(kids_n & 0xFFFFFF);
 #pragma unroll
@@ -777,7 +788,15 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
 #endif
             stop = stop_here();
             if (stop) break;
+#ifdef AQG_STAMP
+            LEVEL_STAMP(8)                                   // request -> state advanced, stop test done (work behind the loads)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            LEVEL_STAMP(9)                                   // ... -> children arrived (what is left of the load latency)
+#endif
             select_level(h, c);
+#ifdef AQG_STAMP
+            LEVEL_STAMP(10)                                  // ... -> child chosen (scores, arg-max, the winner's fields)
+#endif
         }
     }
     at_old_leaf = stop == 3;
@@ -856,11 +875,11 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
 // step -> GNN trunk -> GNN heads (3 kernels instead of select / legal / trunk / heads / expand).
 // ------------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(256) void engine_step_fast_kernel(aqg_engine e, int do_expand, int do_select, int fast_depth) {
-    __shared__ float polbuf[4][256];
+__global__ __launch_bounds__(512) void engine_step_fast_kernel(aqg_engine e, int do_expand, int do_select, int fast_depth) {
+    __shared__ float polbuf[8][256];
     AQG_TRACE_BEGIN
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // 1, 2 or 4 games per workgroup (option "step_waves")
+    const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // 1, 2, 4 or 8 games per workgroup (option "step_waves")
     // a game's wave is a latency-bound chain that issues little: at priority 1 it wins the arbitration against a co-resident trunk
     // workgroup's vector work, finishes sooner and gives its CU's second trunk slot back sooner (option "step_prio")
     { const int pr = (fast_depth >> 8) & 3; if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 3) __builtin_amdgcn_s_setprio(3); }
@@ -897,7 +916,7 @@ static void launch_step(const aqg_engine& e, int do_expand, int do_select, hipSt
     const dim3 grid((e.num_games + 3) / 4), block(256);
     if (g_profile_trunk == 2) profile_mark(st, e.num_games);       // measurement mode 2: the event pairs bracket the step launches
     if (g_step_variant == 1) {
-        const int wpb = g_step_waves == 1 || g_step_waves == 2 ? g_step_waves : 4;
+        const int wpb = (g_step_waves == 1 || g_step_waves == 2 || g_step_waves == 8) ? g_step_waves : 4;
         hipLaunchKernelGGL(engine_step_fast_kernel<N>, dim3((e.num_games + wpb - 1) / wpb), dim3(64 * wpb), 0, st, e, do_expand, do_select, g_step_fast_depth | ((g_step_prio & 3) << 8));
     }
     else hipLaunchKernelGGL(engine_step_kernel<N>, grid, block, 0, st, e, do_expand, do_select);
@@ -1081,7 +1100,7 @@ static int enqueue_sims(const aqg_engine& e, hipStream_t st) {
             // 9x9: the fused trunk; smaller boards: plain kernels over e.gnn_workspace
             if (int r = launch_gcn_forward_boards_any(N, e.leaf_state, 1, e.num_games, e.packed_weights, e.gnn_workspace,
                                                       e.gnn_workspace ? boards_any_workspace_floats(N, e.num_games) : 0, e.pooled, nullptr,
-                                                      e.policy, nullptr, e.value, e.leaf_flag, e.gnn_flags, e.counters + 5, st))
+                                                      e.policy, nullptr, e.value, e.leaf_flag, e.gnn_flags, e.counters + 5, e.heads_sync, st))
                 return r;
         } else {
             hipLaunchKernelGGL(engine_fake_eval_kernel<N>, grid, block, 0, st, e);
@@ -1116,7 +1135,7 @@ template <int N>
 static int run_sims(const aqg_engine& e, hipStream_t st) {
     if (!g_use_graph || g_profile_trunk || st == nullptr || e.sims < 4) return enqueue_sims<N>(e, st);
     // every option a captured launch bakes in is part of the key: a changed option must never replay a stale graph
-    const int opts[8] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth, ((g_trunk_prio & 0xff) << 8) | (g_step_waves << 16) | (g_step_prio << 24) | (g_heads_prio << 28)};
+    const int opts[8] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth, g_heads_in_trunk | ((g_trunk_prio & 0xff) << 8) | (g_step_waves << 16) | (g_step_prio << 24) | (g_heads_prio << 28)};
     for (SimGraph& g : g_sim_graphs)
         if (!memcmp(&g.e, &e, sizeof(aqg_engine)) && !memcmp(g.opts, opts, sizeof(opts))) return replay(g, st);
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {

@@ -22,10 +22,13 @@ for warm_moves, moves in ((0, 4), (20, 4), (60, 4)):
     for _ in range(moves):
         eng.move()
     torch.cuda.synchronize()
-    raw = eng.t["pooled"].view(torch.int64).view(512, 64)[:, :8].double().cpu()
+    raw = eng.t["pooled"].view(torch.int64).view(512, 64)[:, :12].double().cpu()
     steps = raw[:, 7].sum().item()
     names = ["round-1 loads landed", "expand + old backup (issue)", "descent (all levels)", "legal actions of the leaf", "tail stores landed"]
     tot = raw[:, :5].sum().item()
     print(f"after {warm_moves} moves: {steps:.0f} game-steps, {tot / steps:.0f} cycles per step, {raw[:, 6].sum().item() / steps:.2f} levels per descent")
     for i, n in enumerate(names):
         print(f"   {n:30s} {raw[:, i].sum().item() / steps:9.0f} cycles  {100 * raw[:, i].sum().item() / tot:5.1f} %")
+    lv = raw[:, 6].sum().item() - steps * 0          # levels descended (the root level is not stamped: its children came with round 1)
+    for i, n in ((11, "chosen -> next request"), (8, "request -> state advanced"), (9, "... -> children arrived"), (10, "... -> child chosen")):
+        print(f"      per level below the root: {n:28s} {raw[:, i].sum().item() / max(lv, 1):7.0f} cycles")
