@@ -33,7 +33,7 @@ class EngineStruct(_c.Structure):
                               "game_active", "slot_game", "game_plies", "game_result", "game_done", "game_slot", "game_first_move",
                               "legal_order", "legal_count", "pooled", "policy", "value",
                               "hist_state72", "hist_visits", "hist_action",
-                              "counters", "stat_leaf_evals", "stat_terminal_sims", "packed_weights", "gnn_workspace", "heads_sync")]
+                              "counters", "stat_leaf_evals", "stat_terminal_sims", "packed_weights", "gnn_workspace")]
     )
 
 
@@ -62,7 +62,6 @@ SIGNATURES = {
     "aqg_gcn_pack_weights_host": (_c.c_int, [_c.c_int, _c.POINTER(_vp), _vp]),
     "aqg_gcn_forward_boards": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "aqg_gcn_forward_boards_guarded": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp, _vp]),
-    "aqg_gcn_forward_boards_sync": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp, _vp, _vp]),
     "aqg_gcn_boards_any_workspace_floats": (_c.c_size_t, [_c.c_int, _c.c_int]),
     "aqg_gcn_forward_boards_any": (_c.c_int, [_c.c_int, _vp, _c.c_int, _c.c_int, _vp, _vp, _c.c_size_t, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "aqg_gcn_forward_graph": (_c.c_int, [_c.c_int, _c.c_int, _vp, _c.c_int, _vp, _vp, _vp, _vp, _c.c_int, _vp, _vp,

@@ -10,7 +10,6 @@ extern int g_trunk_prio;
 extern int g_heads_prio;
 extern int g_train_fused;
 extern int g_trunk_grid;
-extern int g_heads_in_trunk;
 extern int g_trunk_phase_delay;
 extern int g_trunk_delay_min_boards;
 extern int g_use_graph;
@@ -31,11 +30,11 @@ int launch_state_next(int N, const uint8_t* in, const int32_t* actions, int B, u
 int launch_state_status(int N, const uint8_t* in, int B, int draw, uint8_t* flags, hipStream_t st);
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
-                              int flags, int32_t* saturated, unsigned int* group_sync, hipStream_t st);
+                              int flags, int32_t* saturated, hipStream_t st);
 size_t boards_any_workspace_floats(int N, int B);
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
-                                  float* value, const uint8_t* active, int flags, int32_t* saturated, unsigned int* group_sync, hipStream_t st);
+                                  float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st);
 int launch_gcn_forward_graph(int F, int A, const float* x, int num_nodes, const int32_t* csr_ptr, const int32_t* csr_src,
                              const float* csr_w, const int32_t* graph_ptr, int num_graphs, const float* packed,
                              float* work0, float* work1, float* pooled, float* logits, float* policy, float* value_pre,
@@ -72,7 +71,6 @@ int aqg_set_option(const char* name, int value) {
     if (name && !strcmp(name, "step_waves")) { g_step_waves = value; return 0; }
     if (name && !strcmp(name, "step_variant")) { g_step_variant = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "step_fast_depth")) { if (value < 0 || value > 61) return fail("step_fast_depth must be 0..61"); g_step_fast_depth = value; return 0; }
-    if (name && !strcmp(name, "heads_in_trunk")) { g_heads_in_trunk = value; return 0; }
     if (name && !strcmp(name, "train_fused")) { if (value < 0 || value > 3) return fail("train_fused: 0..3"); g_train_fused = value; return 0; }
     if (name && !strcmp(name, "use_graph")) { g_use_graph = value ? 1 : 0; return 0; }
     if (name && !strcmp(name, "profile_trunk")) { g_profile_trunk = (value == 1 || value == 2) ? value : 0; return 0; }   // 1 = trunk launches, 2 = step launches
@@ -119,7 +117,7 @@ int aqg_gcn_forward_boards(int board_size, const void* states, int state_fmt, in
     if (B < 0 || (B > 0 && (!states || !packed))) return fail("aqg_gcn_forward_boards: bad arguments");
     if (state_fmt != 0 && state_fmt != 1) return fail("aqg_gcn_forward_boards: state_fmt must be 0 or 1");
     return launch_gcn_forward_boards(board_size, states, state_fmt, B, packed, pooled, logits, policy, value_pre, value, nullptr,
-                                     flags, nullptr, nullptr, (hipStream_t)stream);
+                                     flags, nullptr, (hipStream_t)stream);
 }
 
 int aqg_gcn_forward_boards_guarded(int board_size, const void* states, int state_fmt, int B, const float* packed, float* pooled,
@@ -128,16 +126,7 @@ int aqg_gcn_forward_boards_guarded(int board_size, const void* states, int state
     if (B < 0 || (B > 0 && (!states || !packed))) return fail("aqg_gcn_forward_boards_guarded: bad arguments");
     if (state_fmt != 0 && state_fmt != 1) return fail("aqg_gcn_forward_boards_guarded: state_fmt must be 0 or 1");
     return launch_gcn_forward_boards(board_size, states, state_fmt, B, packed, pooled, logits, policy, value_pre, value, nullptr,
-                                     flags, saturated, nullptr, (hipStream_t)stream);
-}
-
-int aqg_gcn_forward_boards_sync(int board_size, const void* states, int state_fmt, int B, const float* packed, float* pooled,
-                                float* logits, float* policy, float* value_pre, float* value, int flags, int32_t* saturated,
-                                uint32_t* group_sync, void* stream) {
-    if (B < 0 || (B > 0 && (!states || !packed))) return fail("aqg_gcn_forward_boards_sync: bad arguments");
-    if (state_fmt != 0 && state_fmt != 1) return fail("aqg_gcn_forward_boards_sync: state_fmt must be 0 or 1");
-    return launch_gcn_forward_boards(board_size, states, state_fmt, B, packed, pooled, logits, policy, value_pre, value, nullptr,
-                                     flags, saturated, group_sync, (hipStream_t)stream);
+                                     flags, saturated, (hipStream_t)stream);
 }
 
 size_t aqg_gcn_boards_any_workspace_floats(int board_size, int B) { return B > 0 ? boards_any_workspace_floats(board_size, B) : 0; }
@@ -148,7 +137,7 @@ int aqg_gcn_forward_boards_any(int board_size, const void* states, int state_fmt
     if (B < 0 || (B > 0 && (!states || !packed))) return fail("aqg_gcn_forward_boards_any: bad arguments");
     if (state_fmt != 0 && state_fmt != 1) return fail("aqg_gcn_forward_boards_any: state_fmt must be 0 or 1");
     return launch_gcn_forward_boards_any(board_size, states, state_fmt, B, packed, workspace, workspace_floats, pooled, logits, policy,
-                                         value_pre, value, nullptr, flags, nullptr, nullptr, (hipStream_t)stream);
+                                         value_pre, value, nullptr, flags, nullptr, (hipStream_t)stream);
 }
 
 int aqg_gcn_forward_graph(int num_features, int num_actions, const float* x, int num_nodes, const int32_t* csr_ptr,

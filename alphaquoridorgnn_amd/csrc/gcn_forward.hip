@@ -819,8 +819,7 @@ __device__ __forceinline__ void request_bias(f32x4 (&out)[6], __amdgpu_buffer_rs
 // (No plane byte is read here: the caller has passed the barrier behind the linear map, the stores are free to go.)
 // No range check here: the caller has bounded layer 2's aggregate by its linear map's output (or the weight set's range is proven),
 // layer 3's aggregate is never split (the heads check the pooled row).
-// SC1: the pooled row is stored at agent scope (written through to memory: workgroups on other XCDs read it a moment later).
-template <bool LAST, bool SC1 = false>
+template <bool LAST>
 __device__ __forceinline__ void aggregate_store(TrunkSmemM& sm, const unsigned int (&AF)[AF_BLOCKS][64][4], u32x4 (&zh)[3], u32x4 (&zl)[3], f32x4 (&out)[6], int wave, int lane,
                                                 const int (&toff)[3], __amdgpu_buffer_rsrc_t pooled_rs, int pooled_soff) {
     constexpr int AHEAD = 3;                                   // adjacency fragments in flight (4 registers each)
@@ -869,7 +868,7 @@ __device__ __forceinline__ void aggregate_store(TrunkSmemM& sm, const unsigned i
         const int col0 = 16 * wave + 4 * (ln >> 4);
         const f32x4 t = row16_sum4(sum);                                  // (the table's entries carry the 1 / (81 CQ) of the mean)
         // (buffer store off an SGPR descriptor + scalar row offset: no 64-bit address registers alive across the board loop)
-        if (c == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), pooled_rs, col0 * 4, pooled_soff, SC1 ? 16 : 0);
+        if (c == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), pooled_rs, col0 * 4, pooled_soff, 0);
     }
 }
 
@@ -1118,9 +1117,9 @@ __device__ __forceinline__ void trunk_bias_offsets(uint64_t hw, uint64_t vw, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// heads on the split matrix pipe: EIGHT waves per 16 boards -- one body, used by the stand-alone heads kernel (any launch size) and
-// by the trunk workgroup that pools the LAST board of a 16-board group (launches of at most HEADS_IN_TRUNK_MAX boards: the MCTS's),
-// so that both paths give bit-identical rows.
+// heads on the split matrix pipe: EIGHT waves per 16 boards.  (Round 4 also ran this body inside the trunk launch -- by the workgroup
+// that pools the last board of a 16-board group, agent-scope stores + one atomic per workgroup, nobody waiting for anybody: correct,
+// and slower, 25.7 against 23.4 us per 480-board evaluation; profiles/r04_heads_by_last_finisher_*.log, commit d13f38b in the history.)
 //   layer 1 (transposed):  hid^T[u][board] = HW1[u][k] pooled^T[k][board]   A = host-split weight fragments (wave w: unit tile w),
 //                          B = this lane's 8 consecutive pooled features of board (lane & 15), split in registers
 //   layer 2:               logits[board][a] = hid[board][u] PW2^T[u][a]     A = the layer-1 accumulators of waves 0..3 (lane = board,
@@ -1151,11 +1150,9 @@ struct alignas(16) HeadsSmem {
     float vlane[4][64];                  // value head: per-lane partial dot products of waves 4..7 (unit tiles 4..7)
     float wmax[HEADS_WAVES][16], wsum[HEADS_WAVES][16];   // per-wave softmax partials per board
 };
-static_assert(sizeof(HeadsSmem) <= PPLANE, "inside the trunk the heads' scratch lives in the (dead) hi plane");
 
 // All 512 threads of a workgroup call this for the 16 boards b0 .. b0 + 15 (two internal barriers).  `prs` = buffer resource of the
-// pooled rows [B][128] f32; SC1 = read them at agent scope (rows stored a moment ago by workgroups on other XCDs).
-template <bool SC1>
+// pooled rows [B][128] f32.
 __device__ __forceinline__ void heads_body(HeadsSmem& sm, __amdgpu_buffer_rsrc_t prs, int b0, int B, int A, __amdgpu_buffer_rsrc_t rs,
                                            const float* __restrict__ pk, float* __restrict__ logits, float* __restrict__ policy,
                                            float* __restrict__ value_pre, float* __restrict__ value, const uint8_t* __restrict__ active,
@@ -1180,24 +1177,50 @@ __device__ __forceinline__ void heads_body(HeadsSmem& sm, __amdgpu_buffer_rsrc_t
                 const int at = wave + 8 * j;
                 bq[j][pl][kb] = (want_policy && at < ntiles) ? load_frag16(rs, lane * 16, P2 + ((pl * 14 + at) * 2 + kb) * (64 * 16)) : (u32x4){0u, 0u, 0u, 0u};
             }
-    // B operand of layer 1: 32 pooled features of board (b0 + c), split
-    u32x4 ph[4], pl_[4];
-    const bool counted = b0 + c < B && !(active && !active[b0 + c]);  // (fp16-range guard) a masked-out board's pooled row is whatever the buffer held
+    // B operand of layer 1: 32 pooled features of board (b0 + c) -- requested now, split below
+    const bool okc = b0 + c < B;
+    f32x4 x0[4], x1[4];
     {
-        const bool ok = b0 + c < B;
-        const int row = (ok ? b0 + c : B - 1) * (HID * 4);
+        const int row = (okc ? b0 + c : B - 1) * (HID * 4);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            x0[kb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, row + (32 * kb + 8 * q) * 4, 0, 0));
+            x1[kb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, row + (32 * kb + 8 * q + 4) * 4, 0, 0));
+        }
+    }
+    // every small operand of the later phases is requested here too, behind the fragments and the pooled rows: behind a barrier each
+    // of them (layer-1 bias, value weights, action biases, the boards' active flags) was a memory round trip of its own in this chain
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(pk + PackedLayout::HB1 + 16 * wave + 4 * q);
+    const f32x4 vw = *reinterpret_cast<const f32x4*>(pk + PackedLayout::VW2 + 16 * (wave & 3) + 4 * q);
+    float pb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int a = 16 * (wave + 8 * j) + c; pb[j] = pk[PackedLayout::PB2 + (a < A ? a : 0)]; }
+    const float vb2 = pk[PackedLayout::VB2];
+    // the boards' active flags: five unconditional byte loads (clamped indices, through a pointer that is never null), all in flight
+    // with everything else -- written as `brd < B && !(active && !active[brd])` each became a branch around a load with its own
+    // s_waitcnt vmcnt(0): five serial round trips
+    const uint8_t* __restrict__ ap = active ? active : reinterpret_cast<const uint8_t*>(pk);
+    unsigned int af4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af4[i] = ap[active ? min(b0 + 4 * q + i, B - 1) : 0];
+    const unsigned int afc = ap[active ? min(b0 + c, B - 1) : 0];
+    u32x4 ph[4], pl_[4];
+    bool counted;
+    {
         float xmax = 0.f;                                              // fp16-range guard (see report_saturation)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            f32x4 x0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, row + (32 * kb + 8 * q) * 4, 0, SC1 ? 16 : 0));
-            f32x4 x1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, row + (32 * kb + 8 * q + 4) * 4, 0, SC1 ? 16 : 0));
-            if (!ok) { x0 = (f32x4){0.f, 0.f, 0.f, 0.f}; x1 = x0; }
+            if (!okc) { x0[kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; x1[kb] = x0[kb]; }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xmax = fmaxf(fmaxf(fabsf(x0[e]), fabsf(x1[e])), xmax);
-            split8(x0, x1, ph[kb], pl_[kb]);
+            for (int e = 0; e < 4; ++e) xmax = fmaxf(fmaxf(fabsf(x0[kb][e]), fabsf(x1[kb][e])), xmax);
+            split8(x0[kb], x1[kb], ph[kb], pl_[kb]);
         }
+        counted = okc && (!active || afc != 0);                        // (fp16-range guard) a masked-out board's pooled row is whatever the buffer held
         if (wave == 0) report_saturation(counted && !(xmax <= 65504.0f), saturated);  // (!(<=) also catches a NaN row; every wave sees the same rows)
     }
+    int live4 = 0;                                             // bit i: board b0 + 4 q + i exists and is not masked out
+#pragma unroll
+    for (int i = 0; i < 4; ++i) live4 |= (b0 + 4 * q + i < B && (!active || af4[i] != 0)) ? (1 << i) : 0;
     // ---- phase 1: hidden units 16 wave + 4 q + e of board b0 + c
     {
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1207,7 +1230,6 @@ __device__ __forceinline__ void heads_body(HeadsSmem& sm, __amdgpu_buffer_rsrc_t
             acc = mfma_f16(af[0][kb], pl_[kb], acc);
             acc = mfma_f16(af[0][kb], ph[kb], acc);
         }
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(pk + PackedLayout::HB1 + 16 * wave + 4 * q);
         f32x4 h = acc + bias;
 #pragma unroll
         for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], 0.f);
@@ -1220,8 +1242,7 @@ __device__ __forceinline__ void heads_body(HeadsSmem& sm, __amdgpu_buffer_rsrc_t
             *reinterpret_cast<u32x2*>(&sm.hfrag[kb2][0][lane][2 * t]) = (u32x2){h01, h23};
             *reinterpret_cast<u32x2*>(&sm.hfrag[kb2][1][lane][2 * t]) = (u32x2){cvt_pk_f16(r[0], r[1]), cvt_pk_f16(r[2], r[3])};
         } else {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(pk + PackedLayout::VW2 + 16 * (wave - 4) + 4 * q);
-            sm.vlane[wave - 4][lane] = h[0] * w[0] + h[1] * w[1] + h[2] * w[2] + h[3] * w[3];
+            sm.vlane[wave - 4][lane] = h[0] * vw[0] + h[1] * vw[1] + h[2] * vw[2] + h[3] * vw[3];
         }
     }
     __syncthreads();
@@ -1229,8 +1250,8 @@ __device__ __forceinline__ void heads_body(HeadsSmem& sm, __amdgpu_buffer_rsrc_t
         float v = (sm.vlane[0][lane] + sm.vlane[1][lane]) + (sm.vlane[2][lane] + sm.vlane[3][lane]);
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
-        if (lane < 16 && b0 + lane < B && !(active && !active[b0 + lane])) {
-            v += pk[PackedLayout::VB2];
+        if (counted && lane < 16) {                            // (lane < 16: c == lane, board b0 + lane)
+            v += vb2;
             if (value_pre) value_pre[b0 + lane] = v;
             if (value) value[b0 + lane] = tanhf(v);
         }
@@ -1256,10 +1277,9 @@ __device__ __forceinline__ void heads_body(HeadsSmem& sm, __amdgpu_buffer_rsrc_t
             acc = mfma_f16(hh[kb], bq[j][0][kb], acc);
         }
         const bool ok = a < A;
-        const float pb = pk[PackedLayout::PB2 + (ok ? a : 0)];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            lg[j][i] = ok ? acc[i] + pb : -INFINITY;
+            lg[j][i] = ok ? acc[i] + pb[j] : -INFINITY;
             m[i] = fmaxf(m[i], lg[j][i]);
         }
     }
@@ -1305,7 +1325,7 @@ __device__ __forceinline__ void heads_body(HeadsSmem& sm, __amdgpu_buffer_rsrc_t
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int brd = b0 + 4 * q + i;
-        if (brd >= B || (active && !active[brd])) continue;
+        if (!((live4 >> i) & 1)) continue;
         const size_t row = (size_t)brd * A + 16 * wave + c;     // one 64-bit address per board row, this wave's tiles at +512 B steps
         if (policy) {
             float* __restrict__ p = policy + row;
@@ -1320,7 +1340,7 @@ __device__ __forceinline__ void heads_body(HeadsSmem& sm, __amdgpu_buffer_rsrc_t
     }
 }
 
-__global__ __launch_bounds__(64 * HEADS_WAVES, 4) void gcn_heads_mm_kernel(float* __restrict__ pooled, int B, int A,
+__global__ __launch_bounds__(64 * HEADS_WAVES, 2) void gcn_heads_mm_kernel(float* __restrict__ pooled, int B, int A,
                                                                            const float* __restrict__ pk, float* __restrict__ logits,
                                                                            float* __restrict__ policy, float* __restrict__ value_pre,
                                                                            float* __restrict__ value, const uint8_t* __restrict__ active, int prio,
@@ -1332,7 +1352,7 @@ __global__ __launch_bounds__(64 * HEADS_WAVES, 4) void gcn_heads_mm_kernel(float
     if (prio == 1) __builtin_amdgcn_s_setprio(1); else if (prio == 2) __builtin_amdgcn_s_setprio(2); else if (prio == 3) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pooled, 0, B * (HID * 4), 0x00020000);
-    heads_body<false>(sm, prs, blockIdx.x * 16, B, A, packed_rsrc(pk), pk, logits, policy, value_pre, value, active, saturated, wave, lane);
+    heads_body(sm, prs, blockIdx.x * 16, B, A, packed_rsrc(pk), pk, logits, policy, value_pre, value, active, saturated, wave, lane);
     AQG_TRACE_END(3, (unsigned long long)(uintptr_t)pooled)
 }
 
@@ -1343,25 +1363,12 @@ __global__ __launch_bounds__(64 * HEADS_WAVES, 4) void gcn_heads_mm_kernel(float
 // pre-clamp outputs by a float maximum; the linear maps' outputs U (which are split themselves) by a float maximum of |U| against the
 // thresholds of PackedLayout::GUARD -- layer 2's aggregate is then below 65504 by  |V| <= 2.0625 max|U| + max|TB|,  layer 3's is not
 // split at all (the heads check the pooled row): one vector instruction per TWO values at three places.
-// HEADS (launches of at most HEADS_IN_TRUNK_MAX boards): the workgroup that pools the LAST board of a 16-board group runs that group's
-// heads (heads_body) before it goes on -- no heads launch in the MCTS's step -> trunk -> heads chain.  Hand-over: every wave stores its
-// 16 pooled features at agent scope (sc1: written through, the group's boards sit on different XCDs) and waits for the
-// acknowledgement; workgroup barrier; ONE agent-scope atomic per workgroup on the group's counter (`group_sync`, caller-owned, zero
-// before the first launch); the workgroup that reads expect - 1 -- expect = the group's ACTIVE boards -- has seen every row of the
-// group stored, reads them at agent scope and resets the counter for the next launch.  Measured cost of the hand-over with 480
-// workgroups in flight (tools/ubench/sync_cost.hip): store + acknowledgement 0.4 us, atomic 0.4 us, remote row 0.2 us.
-// Forward progress: nobody waits for anybody -- a workgroup that is not the last one simply goes on (or exits).
-constexpr int HEADS_IN_TRUNK_MAX = 2048;
-template <int TRACK, bool HEADS>
+template <int TRACK>
 __global__ __launch_bounds__(64 * NWV, 4) void gcn_trunk_boards_mm_kernel(const void* __restrict__ states, int fmt, int B, const float* __restrict__ pk,
                                                                           float* __restrict__ pooled, const uint8_t* __restrict__ active,
-                                                                          int phase_delay, int32_t* __restrict__ saturated,
-                                                                          int A, float* __restrict__ logits, float* __restrict__ policy,
-                                                                          float* __restrict__ value_pre, float* __restrict__ value,
-                                                                          unsigned int* __restrict__ group_sync) {
+                                                                          int phase_delay, int32_t* __restrict__ saturated) {
     AQG_TRACE_BEGIN
     __shared__ TrunkSmemM sm;
-    __shared__ int heads_flag;
     // The two workgroups resident on a CU run identical phase sequences; a start offset for the second-resident ones
     // (phase_delay x 64 cycles) keeps one on the matrix pipe while the other does vector work.
     const int prio_mode = phase_delay >> 16;     // static wave priorities (aqg_set_option("trunk_prio"); chosen by launch size on the host)
@@ -1495,26 +1502,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void gcn_trunk_boards_mm_kernel(const 
         AQG_STAMP_AT(4)
         AQG_STAMP_AT(15)
         phase_prio(6);
-        if constexpr (HEADS) {
-            // the group's active boards (what the counter has to reach): 16 flag bytes, requested in front of the aggregation
-            const int g0 = b & ~15;
-            int act = 1;
-            if (active) { const int ln = fresh_lane(); act = (ln < 16 && g0 + ln < B) ? (int)active[g0 + ln] : 0; }
-            aggregate_store<true, true>(sm, sm.AF, zh, zl, out, wave, lane, toff, prs, b * (HID * 4));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stripe of the pooled row has been acknowledged
-            const int expect = active ? __popcll(__ballot(act != 0)) : min(16, B - g0);
-            __syncthreads();                                           // ... and so have the other seven (and nobody reads the planes any more)
-            if (threadIdx.x == 0) heads_flag = (int)__hip_atomic_fetch_add(group_sync + (b >> 4), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1;
-            __syncthreads();
-            if (heads_flag) {                                          // (workgroup-uniform) every row of the group is in memory
-                if (threadIdx.x == 0) __hip_atomic_store(group_sync + (b >> 4), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                heads_body<true>(*reinterpret_cast<HeadsSmem*>(&sm.P[0][0]), prs, g0, B, A, rs, pk, logits, policy, value_pre, value, active, saturated,
-                                 wave, fresh_lane());
-                __syncthreads();                                       // the scratch is the next board's plane image
-            }
-        } else {
-            aggregate_store<true>(sm, sm.AF, zh, zl, out, wave, lane, toff, prs, b * (HID * 4));
-        }
+        aggregate_store<true>(sm, sm.AF, zh, zl, out, wave, lane, toff, prs, b * (HID * 4));
         rec0 = nrec0; rec1 = nrec1;
         // (No barrier at the end of a board: what the next board writes in front of its top barrier -- the G' rows, wave-private
         //  scratch -- was last read in layer 1 of this board, three barriers back; its planes and adjacency fragments are written
@@ -1669,8 +1657,6 @@ int g_trunk_phase_delay = 100;   // x 64 cycles: start offset of the second-resi
 int g_trunk_delay_min_boards = 2048;   // launches below this many boards start all workgroups together (tools/phase_scan.py:
                                        // +4 % at 2,048 boards, +8 % at 4,096, +15-19 % from 8,192 on the three-per-CU form)
 int g_trunk_grid = 0;      // 0 = default persistent grid; otherwise override (diagnostics)
-int g_heads_in_trunk = 1;  // launches of <= HEADS_IN_TRUNK_MAX boards with a caller-supplied group counter array: the heads of a 16-board group are
-                           // run by the trunk workgroup that pools the group's last board (option "heads_in_trunk", 0 = always a heads launch)
 
 // Diagnostic: fill every CU's LDS with NaN bit patterns so that any read-before-write in a later kernel shows up
 // deterministically (used by the parity tests; LDS contents are otherwise whatever the previous kernel left).
@@ -1730,7 +1716,7 @@ int profile_collect(double* total_ms, long long* launches, long long* boards, in
 
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
-                              int flags, int32_t* saturated, unsigned int* group_sync, hipStream_t st) {
+                              int flags, int32_t* saturated, hipStream_t st) {
     if (N != 9) return fail("fused board trunk is built for 9x9; use aqg_gcn_forward_graph for other sizes");
     if (B <= 0) return 0;
     if (!pooled) return fail("pooled workspace is required");
@@ -1738,7 +1724,6 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
     const int A = N * N + 2 * (N - 1) * (N - 1);
     // persistent grid: 256 CUs x resident workgroups per CU, grid-stride over boards
     const int variant = (flags & 1) ? (g_trunk_variant == 0 ? 0 : 1) : g_trunk_variant;   // AQG_GNN_EXACT_F32
-    bool fused = false;
     if (g_profile_trunk == 1) { (void)hipEventRecord(prof_event(), st); g_prof_boards += B; }
     if (variant == 0) {
         int grid = B < 256 ? B : 256;
@@ -1752,20 +1737,13 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
         const int opts = (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16);
-        const bool want_heads = logits || policy || value_pre || value;
-        const bool proven = (flags & AQG_GNN_RANGE_PROVEN) && saturated;
-        fused = want_heads && group_sync && g_heads_in_trunk == 1 && B <= HEADS_IN_TRUNK_MAX && A <= 14 * 16;
-#define AQG_TRUNK_LAUNCH(TRACK, HEADS) hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<TRACK, HEADS>), dim3(grid), dim3(64 * NWV), 0, st, states, fmt, B, packed, \
-                                                          pooled, active, opts, saturated, A, logits, policy, value_pre, value, group_sync)
-        if (fused) { if (proven) AQG_TRUNK_LAUNCH(0, true); else AQG_TRUNK_LAUNCH(2, true); }
-        else { if (proven) AQG_TRUNK_LAUNCH(0, false); else AQG_TRUNK_LAUNCH(2, false); }
-#undef AQG_TRUNK_LAUNCH
+        if ((flags & AQG_GNN_RANGE_PROVEN) && saturated)
+            hipLaunchKernelGGL(gcn_trunk_boards_mm_kernel<0>, dim3(grid), dim3(64 * NWV), 0, st, states, fmt, B, packed, pooled, active, opts, saturated);
+        else
+            hipLaunchKernelGGL(gcn_trunk_boards_mm_kernel<2>, dim3(grid), dim3(64 * NWV), 0, st, states, fmt, B, packed, pooled, active, opts, saturated);
     }
     if (g_profile_trunk == 1) (void)hipEventRecord(prof_event(), st);
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;
-    if (fused) return 0;                                        // the last finisher of every 16-board group ran its heads
-    { static int probe_ctr = 0;                                 // TIMING-ONLY probe (stale results): 15 of 16 heads launches of small evaluations dropped
-      if (g_heads_in_trunk == 2 && B <= HEADS_IN_TRUNK_MAX && (probe_ctr++ & 15)) return 0; }
     if (!logits && !policy && !value_pre && !value) return 0;   // trunk only (bench: time the dominant kernel alone)
     if (variant >= 3 && A <= 14 * 16) {
         hipLaunchKernelGGL(gcn_heads_mm_kernel, dim3((B + 15) / 16), dim3(64 * HEADS_WAVES), 0, st, pooled, B, A, packed,
@@ -1929,8 +1907,8 @@ size_t boards_any_workspace_floats(int N, int B) { return (size_t)B * N * N * 27
 
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
-                                  float* value, const uint8_t* active, int flags, int32_t* saturated, unsigned int* group_sync, hipStream_t st) {
-    if (N == 9) return launch_gcn_forward_boards(N, states, fmt, B, packed, pooled, logits, policy, value_pre, value, active, flags, saturated, group_sync, st);
+                                  float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st) {
+    if (N == 9) return launch_gcn_forward_boards(N, states, fmt, B, packed, pooled, logits, policy, value_pre, value, active, flags, saturated, st);
     if (!(N == 3 || N == 5 || N == 7)) return fail("board_size must be 3, 5, 7 or 9");
     if (B <= 0) return 0;
     if (!pooled) return fail("pooled workspace is required");

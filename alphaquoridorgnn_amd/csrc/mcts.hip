@@ -32,12 +32,11 @@ int launch_legal_actions(int N, const void* states, int fmt, int B, uint8_t* mas
                          const uint8_t* active, hipStream_t st);
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
-                              int flags, int32_t* saturated, unsigned int* group_sync, hipStream_t st);
+                              int flags, int32_t* saturated, hipStream_t st);
 size_t boards_any_workspace_floats(int N, int B);
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
-                                  float* value, const uint8_t* active, int flags, int32_t* saturated, unsigned int* group_sync, hipStream_t st);
-extern int g_heads_in_trunk;
+                                  float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st);
 extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, g_profile_trunk, g_trunk_prio, g_heads_prio;
 void profile_mark(hipStream_t st, long long units);
 int g_use_graph = 1;       // aqg_set_option("use_graph", 0) forces plain launches
@@ -1100,7 +1099,7 @@ static int enqueue_sims(const aqg_engine& e, hipStream_t st) {
             // 9x9: the fused trunk; smaller boards: plain kernels over e.gnn_workspace
             if (int r = launch_gcn_forward_boards_any(N, e.leaf_state, 1, e.num_games, e.packed_weights, e.gnn_workspace,
                                                       e.gnn_workspace ? boards_any_workspace_floats(N, e.num_games) : 0, e.pooled, nullptr,
-                                                      e.policy, nullptr, e.value, e.leaf_flag, e.gnn_flags, e.counters + 5, e.heads_sync, st))
+                                                      e.policy, nullptr, e.value, e.leaf_flag, e.gnn_flags, e.counters + 5, st))
                 return r;
         } else {
             hipLaunchKernelGGL(engine_fake_eval_kernel<N>, grid, block, 0, st, e);
@@ -1135,7 +1134,7 @@ template <int N>
 static int run_sims(const aqg_engine& e, hipStream_t st) {
     if (!g_use_graph || g_profile_trunk || st == nullptr || e.sims < 4) return enqueue_sims<N>(e, st);
     // every option a captured launch bakes in is part of the key: a changed option must never replay a stale graph
-    const int opts[8] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth, g_heads_in_trunk | ((g_trunk_prio & 0xff) << 8) | (g_step_waves << 16) | (g_step_prio << 24) | (g_heads_prio << 28)};
+    const int opts[8] = {g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, N, g_step_variant, g_step_fast_depth, ((g_trunk_prio & 0xff) << 8) | (g_step_waves << 16) | (g_step_prio << 24) | (g_heads_prio << 28)};
     for (SimGraph& g : g_sim_graphs)
         if (!memcmp(&g.e, &e, sizeof(aqg_engine)) && !memcmp(g.opts, opts, sizeof(opts))) return replay(g, st);
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {

@@ -76,7 +76,6 @@ class BatchedSelfPlay:
         t["counters"] = z((8,), torch.int32)
         t["stat_leaf_evals"] = z((G,), torch.int32)
         t["stat_terminal_sims"] = z((G,), torch.int32)
-        t["heads_sync"] = z(((G + 15) // 16,), torch.int32)   # group counters of the in-trunk heads (include/aqgnn.h, ABI 9): zero, left zero
         if evaluator == "gnn":
             if model is None:
                 raise ValueError("evaluator='gnn' needs a model")
@@ -105,7 +104,6 @@ class BatchedSelfPlay:
                      "stat_leaf_evals", "stat_terminal_sims", "packed_weights"):
             setattr(e, name, t[name].data_ptr())
         e.gnn_workspace = t["gnn_workspace"].data_ptr() if "gnn_workspace" in t else None
-        e.heads_sync = t["heads_sync"].data_ptr()
         self.record_history = record_history
         self.moves_done = 0
         self.reset()

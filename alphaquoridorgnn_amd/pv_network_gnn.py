@@ -223,14 +223,11 @@ class GraphPolicyValueNetwork(nn.Module):
             word = self.saturation_word(dev)
             for attempt in range(2):
                 flags = self.gnn_flags(dev)
-                # up to 2,048 boards the heads run inside the trunk launch (the workgroup that finishes a 16-board group last): the
-                # group counters are this call's own (zero, left zero; never shared with a launch on another stream)
-                sync = torch.zeros(((B + 15) // 16,), dtype=torch.int32, device=dev) if 0 < B <= 2048 else None
-                _lib.check(lib.aqg_gcn_forward_boards_sync(self.board_size, _lib.ptr(states72), state_fmt, B,
-                                                           _lib.ptr(self.packed_weights(dev)), _lib.ptr(pooled), _lib.ptr(logits),
-                                                           _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value), flags,
-                                                           _lib.ptr(word), _lib.ptr(sync), _lib.stream_ptr(dev)),
-                           "aqg_gcn_forward_boards_sync")
+                _lib.check(lib.aqg_gcn_forward_boards_guarded(self.board_size, _lib.ptr(states72), state_fmt, B,
+                                                              _lib.ptr(self.packed_weights(dev)), _lib.ptr(pooled), _lib.ptr(logits),
+                                                              _lib.ptr(policy), _lib.ptr(vpre), _lib.ptr(value), flags,
+                                                              _lib.ptr(word), _lib.stream_ptr(dev)),
+                           "aqg_gcn_forward_boards_guarded")
                 if (flags & _lib.GNN_EXACT_F32) or not check_saturation or B == 0 or int(word.item()) == 0:
                     break
                 self.mark_saturated(dev)          # outside fp16 range: repeat on the exact kernels, and stay there

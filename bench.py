@@ -336,7 +336,7 @@ def main():
 
     if args.trunk_grid:
         _lib.set_option("trunk_grid", args.trunk_grid)
-    for opt in ("step_waves", "trunk_prio", "step_prio", "heads_prio", "heads_in_trunk"):                       # developer knobs through the environment (tools/*_scan.sh)
+    for opt in ("step_waves", "trunk_prio", "step_prio", "heads_prio"):                       # developer knobs through the environment (tools/*_scan.sh)
         if os.environ.get("AQG_" + opt.upper()):
             _lib.set_option(opt, int(os.environ["AQG_" + opt.upper()]))
     if args.trunk_variant != 3:

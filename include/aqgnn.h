@@ -37,8 +37,6 @@ const char* aqg_last_error(void);
  * (hi*hi + hi*lo + lo*hi: fp32-equivalent products; default = the 8-wave x 2-per-CU form, also selected by 6); "step_variant" 1/0 = one-load-round MCTS step / round-1 step, "step_fast_depth" = tree depth at which
  * the fast step hands over to memory mode; "trunk_prio" = static wave priorities in the trunk (-1 = by launch size, default); "step_prio" / "heads_prio" 0..3 = wave
  * priority of the MCTS step / heads kernels (defaults 1 / 3); "step_waves" = games per step workgroup (4);
- * "heads_in_trunk" 1 (default) / 0 = heads of launches of at most 2,048 boards by the trunk workgroup that finishes a 16-board group last
- * (needs the caller's group counters, aqg_gcn_forward_boards_sync / aqg_engine.heads_sync) / always a separate heads launch;
  * "train_fused" = form of the training step
  * (csrc/gcn_train.hip): 2 (default) one workgroup per position with every contraction in fp16 split precision on the 16-bit
  * matrix pipe (9x9 board; a position whose values leave fp16 range is redone in f32 inside the same launch, counted by
@@ -147,16 +145,6 @@ int aqg_gcn_forward_boards(int board_size, const void* states, int state_fmt, in
 int aqg_gcn_forward_boards_guarded(int board_size, const void* states, int state_fmt, int B, const float* packed,
                                    float* pooled, float* logits, float* policy, float* value_pre, float* value,
                                    int flags, int32_t* saturated, void* stream);
-/* The guarded call without a separate heads launch (ABI 9): with `group_sync` -- caller-owned device uint32 [(B + 15) / 16], ZERO before
- * the first call and left zero by every call -- and B <= 2048 on the 9x9 split kernels, the heads of every group of 16 consecutive
- * boards are computed inside the trunk launch by the workgroup that pools the group's last board (a counter per group, agent-scope
- * stores / atomic; nobody waits for anybody).  Same rows, bit for bit, as the two-launch form (one heads body serves both).  A
- * counter array must not be shared by launches that can run concurrently (the engine owns one per game set: aqg_engine.heads_sync).
- * group_sync == NULL, B > 2048, AQG_GNN_EXACT_F32 or option "heads_in_trunk" 0: identical to aqg_gcn_forward_boards_guarded. */
-int aqg_gcn_forward_boards_sync(int board_size, const void* states, int state_fmt, int B, const float* packed,
-                                float* pooled, float* logits, float* policy, float* value_pre, float* value,
-                                int flags, int32_t* saturated, uint32_t* group_sync, void* stream);
-
 /* Same network on an arbitrary batched graph: forward(x, edge_index, batch)  pv_network_gnn.py:53.
  *   x [num_nodes, F] f32;  csr_ptr [num_nodes+1] i32 / csr_src [E'] i32 / csr_w [E'] f32 : incoming edges of
  *   each node INCLUDING self loops with the gcn_norm weights already attached (built by the host wrapper
@@ -221,9 +209,6 @@ typedef struct aqg_engine {
     /* boards other than 9x9 with prior_mode 0: workspace of the any-size forward, aqg_gcn_boards_any_workspace_floats(N, G)
      * floats (may be NULL for 9x9 and for prior_mode 1) */
     float* gnn_workspace;
-    /* (ABI 9) uint32 [(G + 15) / 16], zero: group counters of the in-trunk heads (aqg_gcn_forward_boards_sync); NULL = the trunk is always
-     * followed by a heads launch */
-    uint32_t* heads_sync;
 } aqg_engine;
 
 /* Reset all G slots to the initial position (State() game_logic.py:25-40) and mark them active. */

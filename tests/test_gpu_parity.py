@@ -182,55 +182,6 @@ def test_gnn_forward_boards_vs_fp64_oracle(dev, variant):
     _lib.set_option("trunk_variant", 3)
 
 
-def test_heads_in_trunk_equal_the_heads_launch(dev):
-    """Heads by the last finisher (include/aqgnn.h aqg_gcn_forward_boards_sync, round 4): up to 2,048 boards the heads of a 16-board
-    group are computed inside the trunk launch by the workgroup that pools the group's last board.  One heads body serves both forms,
-    so policy / value / logits / pre-tanh value must equal the two-launch form BIT FOR BIT -- at sizes around the group and grid
-    boundaries (1, 3, 16, 17, 300, 511, 513, 1000, 2048: from one board per workgroup to four), with the guard modes of both trunk
-    builds, LDS poisoned first; the caller's group counters must be back at zero after every launch (a second launch on the same
-    array gives the same rows), and above 2,048 boards the entry falls back to the heads launch."""
-    from alphaquoridorgnn_amd import _lib
-    lib = _lib.load()
-    model, _ = _model(0)
-    pk = model.packed_weights(dev)
-    g = U.golden("walk_9x9.npz")
-    rng = np.random.RandomState(5)
-    word = torch.zeros((1,), dtype=torch.int32, device=dev)
-
-    def run(recs, flags, sync):
-        B = recs.shape[0]
-        out = [torch.full((B, 128), -3.0, device=dev), torch.full((B, 209), -3.0, device=dev), torch.full((B, 209), -3.0, device=dev),
-               torch.full((B,), -3.0, device=dev), torch.full((B,), -3.0, device=dev)]
-        _lib.poison_lds(dev)
-        _lib.check(lib.aqg_gcn_forward_boards_sync(9, _lib.ptr(recs), 0, B, _lib.ptr(pk), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]),
-                                                   _lib.ptr(out[3]), _lib.ptr(out[4]), flags, _lib.ptr(word), _lib.ptr(sync), _lib.stream_ptr(dev)), "sync")
-        return out
-    for B in (1, 3, 16, 17, 300, 511, 513, 1000, 2048, 2300):
-        recs = torch.from_numpy(g["states"][rng.randint(0, g["states"].shape[0], size=B)]).to(dev)
-        sync = torch.zeros(((B + 15) // 16,), dtype=torch.int32, device=dev)
-        for flags in (0, _lib.GNN_RANGE_PROVEN):
-            two = run(recs, flags, None)                      # no counters: trunk launch + heads launch
-            one = run(recs, flags, sync)
-            assert int(sync.abs().sum()) == 0, (B, flags)     # every group's counter was reset by its last finisher
-            again = run(recs, flags, sync)
-            for a, b, c in zip(two, one, again):
-                assert torch.equal(a, b) and torch.equal(a, c), (B, flags)
-            assert bool(torch.isfinite(two[2]).all()) and float(two[2].sum(1).sub(1).abs().max()) < 1e-5
-    assert int(word.item()) == 0
-    # option "heads_in_trunk" 0: the counters are ignored (and stay untouched)
-    _lib.set_option("heads_in_trunk", 0)
-    try:
-        sync = torch.full((19,), 7, dtype=torch.int32, device=dev)
-        recs = torch.from_numpy(g["states"][:300]).to(dev)
-        off = run(recs, 0, sync)
-        assert bool((sync == 7).all())
-    finally:
-        _lib.set_option("heads_in_trunk", 1)
-    on = run(recs, 0, torch.zeros((19,), dtype=torch.int32, device=dev))
-    for a, b in zip(off, on):
-        assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize("variant", [1, 6])
 def test_gnn_forward_scaled_weights(dev, variant):
     """Weights scaled up so activations are O(10): relative tolerance still holds (catches layout slips that
@@ -339,20 +290,6 @@ def test_engine_masked_trunk_launch(dev, variant):
         # mask-free forward of the engine's own packed leaf states (the roots), same kernels: bit-identical rows
         policy, value = model.forward_states(eng.t["leaf_state"][live].contiguous(), state_fmt=1)
         assert torch.equal(eng.t["policy"][live], policy) and torch.equal(eng.t["value"][live], value[:, 0])
-        if variant == 6:
-            # the engine's launch ran the heads inside the trunk (2,048 boards, one counter per 16-board group, masked boards do not
-            # count): the same search with a heads launch behind the trunk gives the same rows, and the counters are back at zero
-            assert int(eng.t["heads_sync"].abs().sum()) == 0
-            pol1, val1, pooled1 = eng.t["policy"].clone(), eng.t["value"].clone(), eng.t["pooled"].clone()
-            _lib.set_option("heads_in_trunk", 0)
-            try:
-                for name in ("pooled", "policy", "value"):
-                    eng.t[name].fill_(-7.25)
-                eng.search(recs)
-                torch.cuda.synchronize()
-            finally:
-                _lib.set_option("heads_in_trunk", 1)
-            assert torch.equal(eng.t["policy"], pol1) and torch.equal(eng.t["value"], val1) and torch.equal(eng.t["pooled"], pooled1)
         keep = ~dead
         np.testing.assert_allclose(eng.t["policy"][live].cpu().numpy(), ref["policy"][idx][keep], atol=1e-6, rtol=1e-4)
         np.testing.assert_allclose(eng.t["value"][live].cpu().numpy(), ref["value"][idx][keep], atol=1e-5, rtol=1e-4)

@@ -28,7 +28,7 @@ def test_capi_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} not bound in _lib.SIGNATURES"
     assert lib.aqg_abi_version() == _lib.ABI_VERSION
     assert lib.aqg_gcn_packed_floats(9) > 64082          # all 64,082 parameters + padding + fragment copies
-    assert ctypes.sizeof(_lib.EngineStruct) == 11 * 4 + 2 * 4 + 4 + 28 * 8   # 13 scalars (+4 pad) + 28 pointers (ABI 9: heads_sync)
+    assert ctypes.sizeof(_lib.EngineStruct) == 11 * 4 + 2 * 4 + 4 + 27 * 8   # 13 scalars (+4 pad) + 27 pointers
     assert ctypes.sizeof(_lib.TrainStruct) == 8 * 4 + 4 * 14 * 8 + 17 * 8      # aqg_train: 8 scalars, 4 x 14 + 17 pointers
 
 
@@ -469,7 +469,7 @@ def test_set_option_names_ranges_and_errors():
     from alphaquoridorgnn_amd import _lib
     lib = _lib.load()
     defaults = {"trunk_variant": 3, "heads_prio": 3, "trunk_prio": -1, "trunk_grid": 0, "trunk_phase_delay": 100, "trunk_delay_min_boards": 2048,
-                "step_prio": 1, "step_waves": 4, "step_variant": 1, "step_fast_depth": None, "heads_in_trunk": 1, "train_fused": 2, "use_graph": 1,
+                "step_prio": 1, "step_waves": 4, "step_variant": 1, "step_fast_depth": None, "train_fused": 2, "use_graph": 1,
                 "profile_trunk": 0}
     header = open(os.path.join(REPO, "include", "aqgnn.h")).read()
     integration = open(os.path.join(REPO, "INTEGRATION.md")).read()

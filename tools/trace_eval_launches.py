@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostic (round 4): one GNN evaluation of AQG_B boards (default 480) as the MCTS makes it -- trunk, then heads -- in its two forms,
-from the -DAQG_TRACE build (every workgroup's start / end on the 100 MHz s_memrealtime clock):
-   two launches : trunk launch, heads launch (8 waves per 16 boards)
-   one launch   : the heads of a 16-board group by the trunk workgroup that pools the group's last board (aqg_gcn_forward_boards_sync)
-Per form: first workgroup start -> last workgroup end of a whole evaluation, the trunk workgroups' durations, and for the one-launch
-form how long the workgroups that ran a group's heads took against those that did not."""
+"""Diagnostic (round 4): one GNN evaluation of AQG_B boards (default 480) as the MCTS makes it -- trunk launch, then heads launch (8 waves
+per 16 boards) -- from the -DAQG_TRACE build (every workgroup's start / end on the 100 MHz s_memrealtime clock): first workgroup start ->
+last workgroup end of a whole evaluation, the trunk workgroups' durations, the heads workgroups' durations.
+(At commit d13f38b this tool also traced the one-launch form -- heads by the trunk workgroup that pools a 16-board group's last board --
+whose result is kept in profiles/r04_heads_by_last_finisher_trace.log: 25.7 against 23.4 us per evaluation.)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,12 +22,11 @@ model = GNNNetwork().to(dev).eval(); pk = model.packed_weights(dev)
 st = synth_states(B)
 pooled = torch.empty((B, 128), device=dev); policy = torch.empty((B, 209), device=dev); value = torch.empty((B,), device=dev)
 flags = model.gnn_flags(dev); word = model.saturation_word(dev)
-sync = torch.zeros(((B + 15) // 16,), dtype=torch.int32, device=dev)
 def fwd(fused):
-    _lib.check(lib.aqg_gcn_forward_boards_sync(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None, _lib.ptr(value), flags,
-                                               _lib.ptr(word), _lib.ptr(sync) if fused else None, _lib.stream_ptr(dev)), "fwd")
+    _lib.check(lib.aqg_gcn_forward_boards_guarded(9, _lib.ptr(st), 0, B, _lib.ptr(pk), _lib.ptr(pooled), None, _lib.ptr(policy), None, _lib.ptr(value), flags,
+                                                  _lib.ptr(word), _lib.stream_ptr(dev)), "fwd")
 CAP = 200_000
-for fused in (False, True, False, True):
+for fused in (False, False):
     for _ in range(10): fwd(fused)
     torch.cuda.synchronize()
     buf = torch.zeros((1 + 4 * CAP,), dtype=torch.int64, device=dev)
