@@ -1161,22 +1161,12 @@ __device__ __forceinline__ void heads_body(HeadsSmem& sm, __amdgpu_buffer_rsrc_t
     constexpr int H1 = (int)(PackedLayout::WHH1 * sizeof(float)), P2 = (int)(PackedLayout::WHP2 * sizeof(float));
     const int ntiles = (A + 15) >> 4;
     const bool want_policy = logits || policy;
-    // this wave's weight fragments: hidden-unit tile `wave` of layer 1, action tiles wave and wave + 8 of layer 2
+    // this wave's weight fragments of layer 1: hidden-unit tile `wave`
     u32x4 af[2][4];                                            // [plane][kb]
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) af[pl][kb] = load_frag16(rs, lane * 16, H1 + ((pl * 8 + wave) * 4 + kb) * (64 * 16));
-    u32x4 bq[2][2][2];                                         // [action tile wave + 8 j][plane][kb2]
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const int at = wave + 8 * j;
-                bq[j][pl][kb] = (want_policy && at < ntiles) ? load_frag16(rs, lane * 16, P2 + ((pl * 14 + at) * 2 + kb) * (64 * 16)) : (u32x4){0u, 0u, 0u, 0u};
-            }
     // B operand of layer 1: 32 pooled features of board (b0 + c) -- requested now, split below
     const bool okc = b0 + c < B;
     f32x4 x0[4], x1[4];
@@ -1221,6 +1211,19 @@ __device__ __forceinline__ void heads_body(HeadsSmem& sm, __amdgpu_buffer_rsrc_t
     int live4 = 0;                                             // bit i: board b0 + 4 q + i exists and is not masked out
 #pragma unroll
     for (int i = 0; i < 4; ++i) live4 |= (b0 + 4 * q + i < B && (!active || af4[i] != 0)) ? (1 << i) : 0;
+    // layer-2 fragments: requested only now, in the registers the raw pooled rows have left (the kernel has to stay inside 128
+    // registers -- eight such waves then fit on a CU beside one trunk workgroup; at 140 registers they did not, and the self-play loop
+    // lost 15 %: 1,468 against 1,720 games/s); they land under layer 1 and the barrier
+    u32x4 bq[2][2][2];                                         // [action tile wave + 8 j][plane][kb2]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int at = wave + 8 * j;
+                bq[j][pl][kb] = (want_policy && at < ntiles) ? load_frag16(rs, lane * 16, P2 + ((pl * 14 + at) * 2 + kb) * (64 * 16)) : (u32x4){0u, 0u, 0u, 0u};
+            }
     // ---- phase 1: hidden units 16 wave + 4 q + e of board b0 + c
     {
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1340,7 +1343,7 @@ __device__ __forceinline__ void heads_body(HeadsSmem& sm, __amdgpu_buffer_rsrc_t
     }
 }
 
-__global__ __launch_bounds__(64 * HEADS_WAVES, 2) void gcn_heads_mm_kernel(float* __restrict__ pooled, int B, int A,
+__global__ __launch_bounds__(64 * HEADS_WAVES, 4) void gcn_heads_mm_kernel(float* __restrict__ pooled, int B, int A,
                                                                            const float* __restrict__ pk, float* __restrict__ logits,
                                                                            float* __restrict__ policy, float* __restrict__ value_pre,
                                                                            float* __restrict__ value, const uint8_t* __restrict__ active, int prio,

@@ -241,8 +241,11 @@ int aqg_engine_root_visits(const aqg_engine* e_host, int32_t* visits, uint8_t* a
 
 /* One optimisation step on a batch of positions: forward, the reference's losses (CrossEntropyLoss applied to the
  * already-softmaxed policy with probability targets train_network.py:54,85 + MSELoss on the tanh value :55,86),
- * backward, and torch.optim.Adam's update (:56,:90-92).  fp32 throughout, every contraction over the node rows on the
- * f32 matrix pipe; two launches per step: one workgroup per position for forward + backward, one fixed-order reduction + Adam (csrc/gcn_train.hip).  mode 0 = gradients only (into grads),
+ * backward, and torch.optim.Adam's update (:56,:90-92).  f32 data and f32 accumulation; two launches per step: one workgroup per
+ * position for forward + backward, one fixed-order reduction + Adam (csrc/gcn_train.hip).  On the 9x9 board (option "train_fused" 2,
+ * the default) every contraction runs on the 16-bit matrix pipe in fp16 hi/lo split precision (three fp16 products per f32
+ * product, the arithmetic of the inference trunk; a position whose values leave fp16 range is redone by the f32-input MFMA body inside
+ * the same launch, aqg_gcn_train_fallbacks counts them); smaller boards and "train_fused" 1 use f32-input MFMA.  mode 0 = gradients only (into grads),
  * 1 = gradients + update, 2 = update only from whatever grads holds -- data-parallel training computes local gradients
  * (mode 0), all-reduces them over RCCL, and applies them (mode 2).  The 14 parameter tensors
  * are the state_dict tensors themselves in their PyTorch layouts and in the key order of KEYS in INTEGRATION.md; grads,
