@@ -464,7 +464,8 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
 #define STEP_STAMP(i)
 #endif
 int g_step_prio = 1;               // wave priority of the fast step kernel (0..3)
-int g_step_waves = 4;              // games (wavefronts) per workgroup of the fast step kernel
+int g_step_waves = 8;              // games (wavefronts) per workgroup of the fast step kernel (1, 2, 4 or 8).  Round 4: 8 -- at 96 registers two step
+                                   // waves per SIMD fit beside one trunk workgroup, half as many workgroups: +0.5-0.8 % games/s at 2,048 and 16,384 games
 int g_step_variant = 1;
 int g_step_fast_depth = 61;
 

@@ -36,7 +36,7 @@ const char* aqg_last_error(void);
 /* tuning knobs: "trunk_variant" 0/1 = exact f32-input MFMA with 1/2 workgroups per CU, 3 = all-MFMA fp16 split trunk
  * (hi*hi + hi*lo + lo*hi: fp32-equivalent products; default = the 8-wave x 2-per-CU form, also selected by 6); "step_variant" 1/0 = one-load-round MCTS step / round-1 step, "step_fast_depth" = tree depth at which
  * the fast step hands over to memory mode; "trunk_prio" = static wave priorities in the trunk (-1 = by launch size, default); "step_prio" / "heads_prio" 0..3 = wave
- * priority of the MCTS step / heads kernels (defaults 1 / 3); "step_waves" = games per step workgroup (4);
+ * priority of the MCTS step / heads kernels (defaults 1 / 3); "step_waves" = games per step workgroup (1, 2, 4 or 8; default 8);
  * "train_fused" = form of the training step
  * (csrc/gcn_train.hip): 2 (default) one workgroup per position with every contraction in fp16 split precision on the 16-bit
  * matrix pipe (9x9 board; a position whose values leave fp16 range is redone in f32 inside the same launch, counted by

@@ -469,7 +469,7 @@ def test_set_option_names_ranges_and_errors():
     from alphaquoridorgnn_amd import _lib
     lib = _lib.load()
     defaults = {"trunk_variant": 3, "heads_prio": 3, "trunk_prio": -1, "trunk_grid": 0, "trunk_phase_delay": 100, "trunk_delay_min_boards": 2048,
-                "step_prio": 1, "step_waves": 4, "step_variant": 1, "step_fast_depth": None, "train_fused": 2, "use_graph": 1,
+                "step_prio": 1, "step_waves": 8, "step_variant": 1, "step_fast_depth": None, "train_fused": 2, "use_graph": 1,
                 "profile_trunk": 0}
     header = open(os.path.join(REPO, "include", "aqgnn.h")).read()
     integration = open(os.path.join(REPO, "INTEGRATION.md")).read()
