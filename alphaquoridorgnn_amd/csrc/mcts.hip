@@ -734,7 +734,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     // s_waitcnt at the back edge -- and what the previous level's choice still owes (next() of the game state, the path, the chosen
     // child's statistics for its lane) is done between the request and the first use: behind the loads, off the level's chain.
     bool at_old_leaf = false;
-#ifdef AQG_STAMP
+#ifdef AQG_STAMP_LEVELS
     unsigned long long lv_prev = __builtin_readcyclecounter();
 #endif
     int stop = stop_here();
@@ -747,7 +747,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
             }
         }
         select_level(hot, cold);          // level 0: the root's children came with round 1
-#ifdef AQG_STAMP
+#ifdef AQG_STAMP_LEVELS
         lv_prev = __builtin_readcyclecounter();
 #endif
         for (;;) {
@@ -763,7 +763,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
             // (Requesting the old path's next child block speculatively, before the scores are computed, was tried: the level
             //  got 14 % SLOWER -- a wrong guess costs a second round.)
             u32x4 h[3], c[3];
-#ifdef AQG_STAMP
+#ifdef AQG_STAMP_LEVELS
             LEVEL_STAMP(11)                                  // child chosen -> next request (hand-over test, addresses)
 #endif
             {
@@ -788,13 +788,13 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
 #endif
             stop = stop_here();
             if (stop) break;
-#ifdef AQG_STAMP
+#ifdef AQG_STAMP_LEVELS
             LEVEL_STAMP(8)                                   // request -> state advanced, stop test done (work behind the loads)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             LEVEL_STAMP(9)                                   // ... -> children arrived (what is left of the load latency)
 #endif
             select_level(h, c);
-#ifdef AQG_STAMP
+#ifdef AQG_STAMP_LEVELS
             LEVEL_STAMP(10)                                  // ... -> child chosen (scores, arg-max, the winner's fields)
 #endif
         }
