@@ -184,7 +184,9 @@ typedef struct aqg_engine {
     int32_t gnn_flags;        /* flags of the GNN forward for prior_mode 0 (AQG_GNN_EXACT_F32 or 0) */
     float c_puct;             /* 1.25  pv_mcts.py:71 */
     float temperature;        /* SP_TEMPERATURE self_play.py:20; 1.0 exact, 0 = argmax */
-    /* tree pool: [G * node_cap] 32-byte node records {f64 w, f32 p, i32 n, u32 first_child|count<<24, u32 action, pad} */
+    /* tree pool: [G * node_cap] 32-byte node records, two aligned 16-byte halves (ABI 9): {f64 w, f32 p, u32 action} -- read only of the
+     * child a descent chooses -- and {i32 n, u32 first_child|count<<24, f32 q = f32(-w/n), f32 cp = f32(c_puct * p)} -- what PUCT
+     * scores every child with (pv_mcts.py:69-78) */
     void* node_rec;
     /* per game, [G] */
     int32_t* node_count; uint8_t* root_state /* [G,24] */; int32_t* path /* [G, sims+2] */; int32_t* path_len;
