@@ -249,46 +249,6 @@ def legal_mask_leg(dev, lib, _lib, synth_states):
     return leg
 
 
-def legal_mask_leg(dev, lib, _lib, synth_states):
-    """SURVEY 8(d) second kernel: batched State.legal_actions() (game_logic.py:103-117, BFS :309-348) -- legal_actions_kernel<9>,
-    one wavefront per state, mask + ordered list + count written.  Every launch sits between its own HIP event pair on the
-    launch stream, so a host hiccup between launches shows up as ONE long sample (max_us) instead of inflating the mean
-    (round 2's unexplained '481 us at B = 512' was the mean of 200 back-to-back launches behind one event pair)."""
-    leg = {"kernel": "legal_actions_kernel<9>", "bound": "integer ALU / latency (not HBM)", "batches": {}}
-    for B in (4096, 65536):
-        st = synth_states(B, seed=1, dev=dev)
-        mask = torch.empty((B, 209), dtype=torch.uint8, device=dev)
-        order = torch.empty((B, 136), dtype=torch.uint8, device=dev)
-        count = torch.empty((B,), dtype=torch.int32, device=dev)
-
-        def legal():
-            _lib.check(lib.aqg_legal_actions(9, _lib.ptr(st), B, _lib.ptr(mask), _lib.ptr(order), _lib.ptr(count), _lib.stream_ptr(dev)), "legal")
-        for _ in range(10):
-            legal()
-        torch.cuda.synchronize()
-        n = 100
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
-        ev[0].record()
-        for i in range(n):
-            legal()
-            ev[i + 1].record()
-        torch.cuda.synchronize()
-        us = np.asarray([ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(n)])
-        med = float(np.median(us))
-        leg["batches"][str(B)] = {"us_per_launch_median": med, "us_min": float(us.min()), "us_max": float(us.max()),
-                                  "states_per_s": B / (med * 1e-6), "hbm_frac": B / (med * 1e-6) * LEGAL_BYTES_PER_STATE / PEAK_HBM,
-                                  "mean_legal_actions": float(count.float().mean()),
-                                  "mean_walls_on_board": float((st[:, 4:68] != 0).sum(1).float().mean())}
-    leg["_sample"] = synth_states(4096, seed=1, dev=dev).cpu().numpy()     # handed to the cpu_baseline leg, removed before printing
-    leg["reference_python_states_per_s_per_core"] = 1e3 / REF_LEGAL_MS_PER_STATE_PY
-    leg["note"] = ("states/s = batch / median launch-to-launch time (HIP event pairs around every launch; max_us is the single worst pair). "
-                   "hbm_frac = states/s x 100 B / 8 TB/s, << 1 by construction: the kernel is integer-ALU and latency bound (up to 128 candidate "
-                   "walls x 2 flood fills), SURVEY 8(d); instruction mix and VALU utilisation from rocprofv3 PMC: profiles/r03_pmc_summary.csv "
-                   "(legal_* rows). The CPU oracle's states/s on 4,096 of the same states is in cpu_baseline.legal_mask_states_per_s_per_core; "
-                   "reference_python = SURVEY 8(d)'s 4.95 ms/state of the real reference measured in the build container")
-    return leg
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
