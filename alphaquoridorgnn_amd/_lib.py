@@ -14,7 +14,7 @@ MAX_LEGAL = 136
 GNN_EXACT_F32 = 1        # AQG_GNN_EXACT_F32 (include/aqgnn.h)
 GNN_RANGE_PROVEN = 2     # AQG_GNN_RANGE_PROVEN
 GNN_PROVEN_MAX_WALLS = 16
-ABI_VERSION = 9
+ABI_VERSION = 10
 TRAIN_PART_FLOATS = 2 * 128 * 128 + 128 * 6 + 3 * 128    # AQG_TRAIN_PART_FLOATS, per position of the batch
 
 _c = ctypes
@@ -33,7 +33,9 @@ class EngineStruct(_c.Structure):
                               "game_active", "slot_game", "game_plies", "game_result", "game_done", "game_slot", "game_first_move",
                               "legal_order", "legal_count", "pooled", "policy", "value",
                               "hist_state72", "hist_visits", "hist_action",
-                              "counters", "stat_leaf_evals", "stat_terminal_sims", "packed_weights", "gnn_workspace")]
+                              "counters", "stat_leaf_evals", "stat_terminal_sims", "packed_weights", "gnn_workspace",
+                              "eval_cache_keys", "eval_cache_rows", "eval_cache_slot", "eval_mask", "stat_cache_hits")]
+        + [("eval_cache_log2", _i32)]
     )
 
 
@@ -67,6 +69,7 @@ SIGNATURES = {
     "aqg_gcn_forward_graph": (_c.c_int, [_c.c_int, _c.c_int, _vp, _c.c_int, _vp, _vp, _vp, _vp, _c.c_int, _vp, _vp,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aqg_engine_reset": (_c.c_int, [_c.POINTER(EngineStruct), _vp]),
+    "aqg_engine_clear_eval_cache": (_c.c_int, [_c.POINTER(EngineStruct), _vp]),
     "aqg_engine_move": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp]),
     "aqg_engine_search": (_c.c_int, [_c.POINTER(EngineStruct), _vp, _vp]),
     "aqg_engine_begin_move": (_c.c_int, [_c.POINTER(EngineStruct), _vp]),

@@ -40,6 +40,7 @@ int launch_gcn_forward_graph(int F, int A, const float* x, int num_nodes, const 
                              float* work0, float* work1, float* pooled, float* logits, float* policy, float* value_pre,
                              float* value, hipStream_t st);
 int engine_reset(const aqg_engine& e, hipStream_t st);
+int engine_clear_eval_cache(const aqg_engine& e, hipStream_t st);
 int engine_begin_move(const aqg_engine& e, hipStream_t st);
 int engine_step(const aqg_engine& e, int do_expand, int do_select, hipStream_t st);
 int engine_finish_move(const aqg_engine& e, const double* uniforms, hipStream_t st);
@@ -153,6 +154,10 @@ int aqg_gcn_forward_graph(int num_features, int num_actions, const float* x, int
 int aqg_engine_reset(const aqg_engine* e, void* stream) {
     if (!e) return fail("aqg_engine_reset: null engine");
     return engine_reset(*e, (hipStream_t)stream);
+}
+int aqg_engine_clear_eval_cache(const aqg_engine* e, void* stream) {
+    if (!e) return fail("aqg_engine_clear_eval_cache: null engine");
+    return engine_clear_eval_cache(*e, (hipStream_t)stream);
 }
 int aqg_engine_move(const aqg_engine* e, const double* uniforms, void* stream) {
     if (!e || !uniforms) return fail("aqg_engine_move: null argument");

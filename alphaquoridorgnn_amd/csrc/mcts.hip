@@ -181,6 +181,7 @@ __global__ void engine_reset_kernel(aqg_engine e) {
     e.leaf_flag[g] = 0;
     e.stat_leaf_evals[g] = 0;
     e.stat_terminal_sims[g] = 0;
+    if (e.eval_cache_keys) { e.stat_cache_hits[g] = 0; e.eval_cache_slot[g] = -1; e.eval_mask[g] = 0; }
 }
 
 __global__ void engine_set_roots_kernel(aqg_engine e, const uint8_t* __restrict__ roots72) {
@@ -463,6 +464,12 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
 #define STEP_STAMP_DECL
 #define STEP_STAMP(i)
 #endif
+constexpr int EVAL_CACHE_ROW = 704;          // f32 priors[MAX_LEGAL] + u8 actions[MAX_LEGAL], padded to 64 bytes (aqgnn.h)
+static_assert(MAX_LEGAL * 5 <= EVAL_CACHE_ROW && MAX_LEGAL % 4 == 0, "evaluation cache row");
+__device__ __forceinline__ uint32_t eval_cache_misc(const QState& s) {
+    return (uint32_t)s.ppos | ((uint32_t)s.pwl << 8) | ((uint32_t)s.epos << 16) | ((uint32_t)s.ewl << 24);
+}
+
 int g_step_prio = 1;               // wave priority of the fast step kernel (0..3)
 int g_step_waves = 8;              // games (wavefronts) per workgroup of the fast step kernel (1, 2, 4 or 8).  Round 4: 8 -- at 96 registers two step
                                    // waves per SIMD fit beside one trunk workgroup, half as many workgroups: +0.5-0.8 % games/s at 2,048 and 16,384 games
@@ -486,8 +493,13 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     uint8_t oa[3] = {0, 0, 0};
     int pnode = 0;
     float polr[4] = {0.f, 0.f, 0.f, 0.f};
+    // evaluation cache (aqgnn.h, ABI 10): a per-slot table of the positions this slot's games have already sent through the network
+    const bool cache_on = e.eval_cache_keys != nullptr && e.prior_mode == 0;
+    int cslot = -1;
+    QState leaf_prev = s_loaded;      // the previous simulation's leaf (its key, when its evaluation goes into the table)
     if (do_expand) {
         flag = e.leaf_flag[g]; depth_old = e.path_len[g]; cnt_new = e.legal_count[g]; first_new = e.node_count[g]; value = e.value[g];
+        if (cache_on) { cslot = e.eval_cache_slot[g]; leaf_prev = load_state(e.leaf_state, 1, g); }
 #pragma unroll
         for (int r = 0; r < 3; ++r) { const int i = lane + 64 * r; oa[r] = (i < MAX_LEGAL) ? ord[i] : (uint8_t)0; }
         pnode = (lane < e.sims + 2) ? path[lane] : 0;
@@ -513,6 +525,10 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     // (wave-uniform values the compiler cannot know to be uniform: as scalars they steer branches and v_readlane)
     flag = __builtin_amdgcn_readfirstlane(flag); depth_old = __builtin_amdgcn_readfirstlane(depth_old);
     cnt_new = __builtin_amdgcn_readfirstlane(cnt_new); first_new = __builtin_amdgcn_readfirstlane(first_new);
+    // leaf_flag 2: the leaf was served from the evaluation cache -- policy[g][0 .. cnt) already holds the renormalised priors over its
+    // legal actions in order (the layout of the other evaluator modes), legal_order / legal_count / value came with them
+    const bool hit_old = flag == 2;
+    if (hit_old) flag = 1;
     if (flag != 1 && !do_select) return;
 #ifdef AQG_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -524,7 +540,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     const int leaf_old = flag == 1 ? (depth_old < 64 ? __builtin_amdgcn_readlane(pnode, depth_old & 63) : path[depth_old]) : -1;
     float pl[3] = {0.f, 0.f, 0.f};
     if (flag == 1) {
-        if (e.prior_mode == 0) {     // P0: gather at the legal actions, divide by the sum unless 0 (pv_network_cnn.py:129-132)
+        if (e.prior_mode == 0 && !hit_old) {     // P0: gather at the legal actions, divide by the sum unless 0 (pv_network_cnn.py:129-132)
 #pragma unroll
             for (int r = 0; r < 4; ++r) polbuf[lane + 64 * r] = polr[r];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -541,9 +557,31 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
             const float den = (sum != 0.f) ? sum : 1.f;
 #pragma unroll
             for (int r = 0; r < 3; ++r) pl[r] = pl[r] / den;
-        } else {                     // fake evaluator: legal-ordered normalised priors
+        } else {                     // fake / external evaluator, or a leaf served from the evaluation cache: legal-ordered normalised priors
 #pragma unroll
             for (int r = 0; r < 3; ++r) { const int i = lane + 64 * r; pl[r] = (i < cnt_new) ? polr[r] : 0.f; }
+        }
+        if (cache_on && !hit_old) {
+            // this evaluation goes into the entry the select step reserved: the row first (priors + actions, defined over all
+            // MAX_LEGAL places), then the key record that makes it findable.  Only this wave ever touches this slot's table.
+            cslot = __builtin_amdgcn_readfirstlane(cslot);
+            if (cslot >= 0) {
+                const size_t ent = ((size_t)g << e.eval_cache_log2) + (size_t)cslot;
+                unsigned char* row = reinterpret_cast<unsigned char*>(e.eval_cache_rows) + ent * EVAL_CACHE_ROW;
+                float* rp = reinterpret_cast<float*>(row);
+                uint8_t* ro = row + MAX_LEGAL * sizeof(float);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int i = lane + 64 * r;
+                    if (i < MAX_LEGAL) { rp[i] = pl[r]; ro[i] = (i < cnt_new) ? oa[r] : (uint8_t)0xFF; }
+                }
+                if (lane == 0) {
+                    const QState k = uniform_state(leaf_prev);
+                    u32x4* kr = reinterpret_cast<u32x4*>(e.eval_cache_keys) + 2 * ent;
+                    kr[0] = (u32x4){(uint32_t)k.hw, (uint32_t)(k.hw >> 32), (uint32_t)k.vw, (uint32_t)(k.vw >> 32)};
+                    kr[1] = (u32x4){eval_cache_misc(k), 2u, (uint32_t)cnt_new, __builtin_bit_cast(uint32_t, value)};
+                }
+            }
         }
         if (expanded) {
 #pragma unroll
@@ -597,8 +635,8 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
         }
     }
     if (!do_select) { flush_old(); return; }
-    if (!active) { flush_old(); if (lane == 0) e.leaf_flag[g] = 0; return; }
-    if (lane == 0) e.leaf_flag[g] = 0;
+    if (!active) { flush_old(); if (lane == 0) { e.leaf_flag[g] = 0; if (cache_on) e.eval_mask[g] = 0; } return; }
+    if (lane == 0) { e.leaf_flag[g] = 0; if (cache_on) e.eval_mask[g] = 0; }
     STEP_STAMP(1)
 
     // ---------------- descent (pv_mcts.py:33-66 via :69-78)
@@ -851,13 +889,64 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
         }
     } else {
         flush_old();
-        const int total = wave_legal_actions<N>(s, lane, nullptr, e.legal_order + (size_t)g * MAX_LEGAL);
-        STEP_STAMP(3)
-        if (lane == 0) {
-            store_state(e.leaf_state, g, s);
-            e.legal_count[g] = total;
-            e.path_len[g] = depth;
-            e.leaf_flag[g] = 1;
+        // Evaluation cache: has this slot asked the network for this position before?  One probe round -- lane i compares the key
+        // record of table entry (home + i) -- decides; a hit copies the entry's priors, actions, count and value to where the
+        // evaluator and wave_legal_actions would have put them, and the leaf is sent neither through the legal-move search nor
+        // through the network (eval_mask 0).  A miss reserves the first empty entry of the window (or replaces one) for the
+        // evaluation that the next step's expansion will see.
+        bool hit = false;
+        int newslot = -1;
+        if (cache_on) {
+            const uint32_t misc = eval_cache_misc(s);
+            uint64_t h = s.hw * 0x9E3779B97F4A7C15ull ^ s.vw * 0xC2B2AE3D27D4EB4Full ^ (uint64_t)misc * 0x165667B19E3779F9ull;
+            h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+            const uint32_t cmask = (1u << e.eval_cache_log2) - 1u, home = (uint32_t)h & cmask;
+            const size_t base = (size_t)g << e.eval_cache_log2;
+            const u32x4* keys = reinterpret_cast<const u32x4*>(e.eval_cache_keys) + 2 * base;
+            const uint32_t idx = (home + (uint32_t)lane) & cmask;
+            const u32x4 k0 = keys[2 * idx], k1 = keys[2 * idx + 1];
+            // (elements through scalars: __builtin_bit_cast / readlane of a vector ELEMENT expression reads element 0 with hipcc 7.2)
+            const uint32_t a0 = k0[0], a1 = k0[1], a2 = k0[2], a3 = k0[3], b0 = k1[0], b1 = k1[1], b2 = k1[2], b3 = k1[3];
+            const bool match = a0 == (uint32_t)s.hw && a1 == (uint32_t)(s.hw >> 32) && a2 == (uint32_t)s.vw && a3 == (uint32_t)(s.vw >> 32) &&
+                               b0 == misc && b1 == 2u;
+            const uint64_t mb = __ballot(match);
+            if (mb) {
+                hit = true;
+                const int src = __builtin_ctzll(mb);
+                const uint32_t hs = (home + (uint32_t)src) & cmask;
+                const int cnt = __builtin_amdgcn_readlane((int)b2, src);
+                const uint32_t vbits = (uint32_t)__builtin_amdgcn_readlane((int)b3, src);
+                const unsigned char* row = reinterpret_cast<const unsigned char*>(e.eval_cache_rows) + (base + hs) * EVAL_CACHE_ROW;
+                const float* rp = reinterpret_cast<const float*>(row);
+                float* pdst = e.policy + (size_t)g * A;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { const int i = lane + 64 * r; if (i < cnt) pdst[i] = rp[i]; }
+                if (lane < MAX_LEGAL / 4)
+                    reinterpret_cast<uint32_t*>(e.legal_order + (size_t)g * MAX_LEGAL)[lane] = reinterpret_cast<const uint32_t*>(row + MAX_LEGAL * sizeof(float))[lane];
+                STEP_STAMP(3)
+                if (lane == 0) {
+                    store_state(e.leaf_state, g, s);
+                    e.legal_count[g] = cnt;
+                    e.path_len[g] = depth;
+                    e.value[g] = __builtin_bit_cast(float, vbits);
+                    e.leaf_flag[g] = 2;
+                    e.stat_cache_hits[g] += 1;
+                }
+            } else {
+                const uint64_t eb = __ballot(b1 == 0u);
+                newslot = (int)((home + (uint32_t)(eb ? __builtin_ctzll(eb) : (int)((h >> 40) & 63u))) & cmask);
+            }
+        }
+        if (!hit) {
+            const int total = wave_legal_actions<N>(s, lane, nullptr, e.legal_order + (size_t)g * MAX_LEGAL);
+            STEP_STAMP(3)
+            if (lane == 0) {
+                store_state(e.leaf_state, g, s);
+                e.legal_count[g] = total;
+                e.path_len[g] = depth;
+                e.leaf_flag[g] = 1;
+                if (cache_on) { e.eval_mask[g] = 1; e.eval_cache_slot[g] = newslot; }
+            }
         }
     }
 #ifdef AQG_STAMP
@@ -1086,6 +1175,12 @@ static int validate(const aqg_engine& e) {
     if (e.prior_mode < 0 || e.prior_mode > 2) return fail("prior_mode must be 0, 1 or 2");
     if (e.quota < e.num_games) return fail("quota must be >= num_games");
     if (!e.slot_game || !e.game_done || !e.game_slot || !e.game_first_move) return fail("slot_game / game_done / game_slot / game_first_move are required");
+    if (e.eval_cache_keys) {
+        if (e.prior_mode != 0) return fail("the evaluation cache serves the GNN evaluator only (prior_mode 0)");
+        if (!e.eval_cache_rows || !e.eval_cache_slot || !e.eval_mask || !e.stat_cache_hits) return fail("eval_cache_rows / eval_cache_slot / eval_mask / stat_cache_hits are required with eval_cache_keys");
+        if (e.eval_cache_log2 < 6 || e.eval_cache_log2 > 20) return fail("eval_cache_log2 must be 6..20");
+        if (g_step_variant != 1) return fail("the evaluation cache needs step_variant 1");
+    }
     return 0;
 }
 
@@ -1100,7 +1195,7 @@ static int enqueue_sims(const aqg_engine& e, hipStream_t st) {
             // 9x9: the fused trunk; smaller boards: plain kernels over e.gnn_workspace
             if (int r = launch_gcn_forward_boards_any(N, e.leaf_state, 1, e.num_games, e.packed_weights, e.gnn_workspace,
                                                       e.gnn_workspace ? boards_any_workspace_floats(N, e.num_games) : 0, e.pooled, nullptr,
-                                                      e.policy, nullptr, e.value, e.leaf_flag, e.gnn_flags, e.counters + 5, st))
+                                                      e.policy, nullptr, e.value, e.eval_cache_keys ? e.eval_mask : e.leaf_flag, e.gnn_flags, e.counters + 5, st))
                 return r;
         } else {
             hipLaunchKernelGGL(engine_fake_eval_kernel<N>, grid, block, 0, st, e);
@@ -1208,8 +1303,16 @@ int engine_finish_move(const aqg_engine& e, const double* uniforms, hipStream_t 
     return check_launch("engine_finish_move_kernel");
 }
 
+int engine_clear_eval_cache(const aqg_engine& e, hipStream_t st) {
+    if (int r = validate(e)) return r;
+    if (!e.eval_cache_keys) return 0;
+    if (hipMemsetAsync(e.eval_cache_keys, 0, ((size_t)e.num_games << e.eval_cache_log2) * 32, st) != hipSuccess) return fail("hipMemsetAsync(eval_cache_keys)");
+    return 0;
+}
+
 int engine_reset(const aqg_engine& e, hipStream_t st) {
     if (int r = validate(e)) return r;
+    if (int r = engine_clear_eval_cache(e, st)) return r;
     hipLaunchKernelGGL(engine_reset_kernel, dim3((max(e.num_games, e.quota) + 255) / 256), dim3(256), 0, st, e);
     return check_launch("engine_reset_kernel");
 }

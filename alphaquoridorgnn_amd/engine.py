@@ -20,12 +20,16 @@ from .constants import BOARD_SIZE, board_params
 
 class BatchedSelfPlay:
     def __init__(self, model=None, num_games=2048, sims=50, board_size=BOARD_SIZE, device=None, temperature=1.0,
-                 c_puct=1.25, evaluator="gnn", fake_bias=0, seed=0, record_history=True, quota=None):
+                 c_puct=1.25, evaluator="gnn", fake_bias=0, seed=0, record_history=True, quota=None, eval_cache_slots=0):
         """model: GraphPolicyValueNetwork/GNNNetwork (evaluator='gnn'); evaluator='fake' runs the integer-hash
         evaluator used by the parity tests (oracle/mcts.py FakeModel); evaluator='external' calls `model.predict(state,
         device)` -- ANY object honouring the reference's BaseNetwork contract (BaseNetwork.py:36-40), e.g. a stock CNN --
         once per simulation and game from the host, exactly like pv_mcts.py:47 (plumbing path: one host round trip per
-        simulation)."""
+        simulation).
+        eval_cache_slots (evaluator='gnn' only; a power of two >= 64, 0 = off): entries per game slot of the evaluation cache
+        (include/aqgnn.h, `eval_cache_keys`): a leaf whose position this slot has already sent through the network is expanded from
+        the stored priors / value / legal list -- bit-identical searches and game records, fewer network evaluations (736 bytes of
+        HBM per entry)."""
         self.dev = _lib.require_gpu(device)
         self.lib = _lib.load()
         self.N = board_size
@@ -89,6 +93,18 @@ class BatchedSelfPlay:
             t["packed_weights"] = z((4,), torch.float32)
             self._gnn_flags = 0
 
+        self.eval_cache_slots = int(eval_cache_slots)
+        if self.eval_cache_slots:
+            if evaluator != "gnn":
+                raise ValueError("eval_cache_slots needs evaluator='gnn' (the table stores network outputs)")
+            if self.eval_cache_slots < 64 or self.eval_cache_slots & (self.eval_cache_slots - 1) or self.eval_cache_slots > (1 << 20):
+                raise ValueError("eval_cache_slots must be a power of two in 64 .. 2**20")
+            t["eval_cache_keys"] = z((G * self.eval_cache_slots, 32), torch.uint8)
+            t["eval_cache_rows"] = torch.empty((G * self.eval_cache_slots, 704), dtype=torch.uint8, device=dev)
+            t["eval_cache_slot"] = torch.full((G,), -1, dtype=torch.int32, device=dev)
+            t["eval_mask"] = z((G,), torch.uint8)
+            t["stat_cache_hits"] = z((G,), torch.int32)
+
         e = self.e = _lib.EngineStruct()
         e.board_size, e.num_walls, e.plies_for_draw = self.N, self.num_walls, self.plies_for_draw
         e.num_games, e.quota, e.sims, e.node_cap = G, Q, self.sims, cap
@@ -104,6 +120,10 @@ class BatchedSelfPlay:
                      "stat_leaf_evals", "stat_terminal_sims", "packed_weights"):
             setattr(e, name, t[name].data_ptr())
         e.gnn_workspace = t["gnn_workspace"].data_ptr() if "gnn_workspace" in t else None
+        if self.eval_cache_slots:
+            for name in ("eval_cache_keys", "eval_cache_rows", "eval_cache_slot", "eval_mask", "stat_cache_hits"):
+                setattr(e, name, t[name].data_ptr())
+            e.eval_cache_log2 = self.eval_cache_slots.bit_length() - 1
         self.record_history = record_history
         self.moves_done = 0
         self.reset()
@@ -121,6 +141,8 @@ class BatchedSelfPlay:
             self.t["packed_weights"] = self.model.packed_weights(self.dev)
             self.e.packed_weights = self.t["packed_weights"].data_ptr()
             self.e.gnn_flags = int(self.model.gnn_flags(self.dev))
+            if self.eval_cache_slots:      # the table holds the OLD weights' outputs
+                _lib.check(self.lib.aqg_engine_clear_eval_cache(ctypes.byref(self.e), self._stream()), "aqg_engine_clear_eval_cache")
 
     def move(self, uniforms=None):
         """One move for every active game.  uniforms: float64 [G] in [0,1) (default: device RNG stream)."""
@@ -179,6 +201,7 @@ class BatchedSelfPlay:
         return dict(active=int(c[0]), finished=int(c[1]), dead_ends=int(c[2]), started=int(c[3]), moves=int(c[4]),
                     gnn_saturated=int(c[5]),      # the split kernels' fp16-range guard fired during this generation (aqgnn.h counters[5])
                     leaf_evals=int(self.t["stat_leaf_evals"].sum().item()),
+                    cache_hits=int(self.t["stat_cache_hits"].sum().item()) if self.eval_cache_slots else 0,
                     terminal_sims=int(self.t["stat_terminal_sims"].sum().item()))
 
     def _fall_back_to_exact_kernels(self):
@@ -234,6 +257,8 @@ class BatchedSelfPlay:
             self._gnn_flags = _lib.GNN_EXACT_F32
             self.e.gnn_flags = _lib.GNN_EXACT_F32
             self.t["counters"][5] = 0
+            if self.eval_cache_slots:      # the table holds the clamped evaluations of the split kernels
+                _lib.check(self.lib.aqg_engine_clear_eval_cache(ctypes.byref(self.e), self._stream()), "aqg_engine_clear_eval_cache")
         visits = torch.empty((self.G, _lib.MAX_LEGAL), dtype=torch.int32, device=self.dev)
         actions = torch.empty((self.G, _lib.MAX_LEGAL), dtype=torch.uint8, device=self.dev)
         count = torch.empty((self.G,), dtype=torch.int32, device=self.dev)
@@ -365,7 +390,7 @@ class MultiSetSelfPlay:
         return self._live[k]
 
     def counters(self):
-        tot = dict(active=0, finished=0, dead_ends=0, started=0, moves=0, gnn_saturated=0, leaf_evals=0, terminal_sims=0)
+        tot = dict(active=0, finished=0, dead_ends=0, started=0, moves=0, gnn_saturated=0, leaf_evals=0, cache_hits=0, terminal_sims=0)
         for i, eng in self._each():
             c = eng.counters()                    # .cpu() inside synchronises this set's stream only
             self._live[i] = self._live[i] and c["active"] > 0

@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define AQG_MAX_LEGAL 136 /* >= 5 pawn moves + 128 wall placements */
-#define AQG_ABI_VERSION 9
+#define AQG_ABI_VERSION 10
 
 int aqg_abi_version(void);
 const char* aqg_last_error(void);
@@ -211,10 +211,28 @@ typedef struct aqg_engine {
     /* boards other than 9x9 with prior_mode 0: workspace of the any-size forward, aqg_gcn_boards_any_workspace_floats(N, G)
      * floats (may be NULL for 9x9 and for prior_mode 1) */
     float* gnn_workspace;
+    /* Evaluation cache (ABI 10; prior_mode 0 only; eval_cache_keys == NULL: off).  The reference builds a new tree for every move
+     * (pv_mcts.py:84) and keeps no transposition table, so a game asks model.predict (pv_mcts.py:47) for the same position again and
+     * again: transpositions inside a search, and the sub-tree of the move that was played in the next search.  The network's output and
+     * legal_actions() are pure functions of (walls, pawns, walls in hand) -- not of the ply counter -- and the fused kernels compute every
+     * board independently of its launch, so a per-slot table keyed by those 20 bytes returns bit-identical priors, values and legal
+     * lists: the search, the visit counts and the game records do not change, only the leaf is not sent through the network (nor through
+     * the legal-move kernel) again.  Per slot 1 << eval_cache_log2 entries: a 32-byte key record {u64 hw, u64 vw, u32 ppos|pwl<<8|
+     * epos<<16|ewl<<24, u32 state (0 empty, 2 filled), i32 legal count, f32 value} + a 704-byte row {f32 priors[AQG_MAX_LEGAL] over
+     * legal_actions() in order, renormalised (pv_network_cnn.py:129-132), u8 actions[AQG_MAX_LEGAL]}.  A slot keeps its table over its
+     * games (positions stay valid); aqg_engine_reset clears it, and so must the caller when the weights change
+     * (aqg_engine_clear_eval_cache).  leaf_flag[g] == 2 marks a leaf that was served from the table; eval_mask[g] == 1 the leaves the
+     * network evaluates (the `active` mask of the GNN launches). */
+    void* eval_cache_keys; void* eval_cache_rows;
+    int32_t* eval_cache_slot /* [G] entry reserved for the pending evaluation, -1 none */; uint8_t* eval_mask /* [G] */;
+    int32_t* stat_cache_hits /* [G] */;
+    int32_t eval_cache_log2;
 } aqg_engine;
 
-/* Reset all G slots to the initial position (State() game_logic.py:25-40) and mark them active. */
+/* Reset all G slots to the initial position (State() game_logic.py:25-40) and mark them active; clears the evaluation cache. */
 int aqg_engine_reset(const aqg_engine* e_host, void* stream);
+/* Empty the evaluation cache of every slot (after a weight update). */
+int aqg_engine_clear_eval_cache(const aqg_engine* e_host, void* stream);
 /* One self-play move for every active game == pv_mcts_policy (pv_mcts.py:20-95, `sims` lock-step simulations:
  * select :69-78, terminal/leaf evaluate :33-57, backup) + the body of play() (self_play.py:45-60): record
  * (state, visit counts), sample the action with uniforms[g] exactly like np.random.choice (self_play.py:57),
