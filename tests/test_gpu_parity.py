@@ -1749,6 +1749,126 @@ def test_search_and_match_replay_on_exact_kernels_after_range_guard(dev):
 
 
 @pytest.mark.gpu
+# ------------------------------------------------------------------ evaluation cache (ABI 10)
+def _generation(model, slots, **kw):
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay
+    eng = BatchedSelfPlay(model, eval_cache_slots=slots, **kw)
+    c = eng.play_generation()
+    rows = tuple(x.cpu() for x in eng.history_tensors())
+    per_game = tuple(eng.t[k].cpu() for k in ("game_plies", "game_result", "game_slot", "game_first_move", "hist_action"))
+    return eng, c, rows + per_game
+
+
+@pytest.mark.parametrize("N,slots", [(9, 4096), (9, 64), (5, 256)])
+def test_eval_cache_generation_bit_identical(dev, N, slots):
+    """The evaluation cache (include/aqgnn.h `eval_cache_keys`; the reference re-predicts every leaf, pv_mcts.py:47, and builds a new
+    tree per move, :84) must not change one byte of a generation: history rows, results, actions, plies and the number of LOGICAL
+    evaluations are those of the cache-less engine -- with a roomy table, with a table so small (64 entries = one probe window) that
+    entries are replaced all the time, and on a small board (the any-size forward takes the same mask)."""
+    model, _ = _model(2) if N == 9 else (None, None)
+    if N != 9:
+        from alphaquoridorgnn_amd.pv_network_gnn import GraphPolicyValueNetwork
+        from oracle import gnn as og
+        model = GraphPolicyValueNetwork(6, 128, 3, N * N + 2 * (N - 1) ** 2, board_size=N)
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in og.init_params(1, N=N).items()})
+        model = model.to(dev).eval()
+    kw = dict(num_games=40, sims=24, board_size=N, seed=11)
+    _, c0, ref = _generation(model, 0, **kw)
+    eng, c1, got = _generation(model, slots, **kw)
+    assert c0["cache_hits"] == 0 and c1["cache_hits"] > 0.2 * c1["leaf_evals"], (c0, c1)
+    for k in ("finished", "leaf_evals", "terminal_sims", "dead_ends"):
+        assert c0[k] == c1[k], k
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    # leaf_flag 2 / eval_mask: what the GNN launches of the last simulation were asked to evaluate is a subset of the leaves
+    lf, em = eng.t["leaf_flag"].cpu().numpy(), eng.t["eval_mask"].cpu().numpy()
+    assert ((em == 1) <= (lf == 1)).all() and not ((lf == 2) & (em != 0)).any()
+
+
+def test_eval_cache_search_served_from_table_vs_oracle(dev):
+    """A search whose every position is already in the table (the same roots searched twice) must still expand its leaves with the
+    oracle's priors in legal_actions() order and distribute its visits like oracle.mcts -- the cached row IS the evaluation."""
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay
+    from oracle import gnn as og, mcts as om, quoridor as oq
+    model, params = _model(4)
+    oracle = og.OracleModel(params)
+    g = U.golden("walk_9x9.npz")
+    recs = np.stack([g["states"][i] for i in [0, 5, 40, 333, 1200, 2600, 5000, 9000]])
+    recs = recs[[not (oq.State(r).is_done()) for r in recs]]
+    sims = 10
+    eng = BatchedSelfPlay(model, num_games=recs.shape[0], sims=sims, record_history=False, eval_cache_slots=256)
+    eng.search(recs)
+    first = eng.counters()
+    eng.search(recs)
+    torch.cuda.synchronize()
+    second = eng.counters()
+    # every evaluation of the second search is a hit (same roots, same deterministic search)
+    assert second["cache_hits"] - first["cache_hits"] == second["leaf_evals"] - first["leaf_evals"] > 0
+    for rec, (pri, vis, act) in zip(recs, _root_children(eng)):
+        st = oq.State(rec)
+        assert [int(a) for a in act] == [int(a) for a in st.legal_actions()]
+        want, _ = oracle.predict(st)
+        np.testing.assert_allclose(pri, want, atol=1e-6, rtol=1e-5)
+        root = om.search(oracle, st, sims)
+        assert [int(v) for v in vis] == [c.n for c in root.children]
+
+
+def test_eval_cache_refill_weights_and_range_guard(dev):
+    """The table over a slot's lifetime: (1) slot refill -- a slot keeps its table over its games (positions stay valid) and every game
+    is the cache-less one; (2) new weights: refresh_weights() empties the table (its rows are the OLD network's outputs) -- a
+    generation after the update equals a fresh engine's; (3) the fp16-range guard: the replay on the exact kernels starts from an
+    empty table (the clamped evaluations must not survive) and equals the cache-less replay; (4) several game sets."""
+    from alphaquoridorgnn_amd import _lib
+    from alphaquoridorgnn_amd.engine import BatchedSelfPlay, MultiSetSelfPlay
+    model, _ = _model(6)
+    kw = dict(num_games=6, quota=15, sims=10, seed=2)
+    _, c0, ref = _generation(model, 0, **kw)
+    _, c1, got = _generation(model, 512, **kw)
+    assert c0["finished"] == c1["finished"] == 15 and c1["cache_hits"] > 0
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    # (2)
+    eng = BatchedSelfPlay(model, num_games=8, sims=10, seed=5, eval_cache_slots=512)
+    eng.play_generation()
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.mul_(1.25)
+    model.invalidate_packed() if hasattr(model, "invalidate_packed") else None
+    eng.refresh_weights()
+    eng.reset()
+    eng.gen.manual_seed(5)
+    eng.play_generation()
+    fresh = BatchedSelfPlay(model, num_games=8, sims=10, seed=5)
+    fresh.play_generation()
+    for a, b in zip(eng.history_tensors(), fresh.history_tensors()):
+        assert torch.equal(a, b)
+    # (3) the same forced replay with and without the table (two copies of the weight set: the first replay marks its model)
+    hist = []
+    for slots in (256, 0):
+        model3, _ = _model(5)
+        a = BatchedSelfPlay(model3, num_games=6, sims=6, seed=3, eval_cache_slots=slots)
+        for _ in range(3):
+            a.move()
+        a.t["counters"][5] = 1
+        ca = a.play_generation()
+        assert a.e.gnn_flags == _lib.GNN_EXACT_F32 and ca["finished"] == 6 and (ca["cache_hits"] > 0) == (slots > 0)
+        hist.append(a.history_tensors())
+    for x, y in zip(*hist):
+        assert torch.equal(x, y)
+    # (4)
+    model4, _ = _model(7)
+    m0 = MultiSetSelfPlay(model4, num_games=24, sims=8, num_sets=3, seed=9)
+    m1 = MultiSetSelfPlay(model4, num_games=24, sims=8, num_sets=3, seed=9, eval_cache_slots=256)
+    c0, c1 = m0.play_generation(), m1.play_generation()
+    assert c1["cache_hits"] > 0 and c0["leaf_evals"] == c1["leaf_evals"]
+    for x, y in zip(m0.history_tensors(), m1.history_tensors()):
+        assert torch.equal(x, y)
+    with pytest.raises(ValueError):
+        BatchedSelfPlay(None, num_games=2, sims=4, evaluator="fake", eval_cache_slots=64)
+    with pytest.raises(ValueError):
+        BatchedSelfPlay(model4, num_games=2, sims=4, eval_cache_slots=100)
+
+
 def test_graft_entry_smoke():
     """The driver's smoke step (legal mask, GNN forward, MCTS, a tiny generation against the oracle) stays runnable."""
     import __graft_entry__
