@@ -34,7 +34,7 @@ class EngineStruct(_c.Structure):
                               "legal_order", "legal_count", "pooled", "policy", "value",
                               "hist_state72", "hist_visits", "hist_action",
                               "counters", "stat_leaf_evals", "stat_terminal_sims", "packed_weights", "gnn_workspace",
-                              "eval_cache_keys", "eval_cache_rows", "eval_cache_slot", "eval_mask", "stat_cache_hits")]
+                              "eval_cache_keys", "eval_cache_rows", "eval_cache_slot", "eval_mask", "stat_cache_hits", "eval_list", "eval_count")]
         + [("eval_cache_log2", _i32)]
     )
 

@@ -30,11 +30,11 @@ int launch_state_next(int N, const uint8_t* in, const int32_t* actions, int B, u
 int launch_state_status(int N, const uint8_t* in, int B, int draw, uint8_t* flags, hipStream_t st);
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
-                              int flags, int32_t* saturated, hipStream_t st);
+                              int flags, int32_t* saturated, hipStream_t st, const int32_t* list = nullptr, const int32_t* list_count = nullptr);
 size_t boards_any_workspace_floats(int N, int B);
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
-                                  float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st);
+                                  float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st, const int32_t* list = nullptr, const int32_t* list_count = nullptr);
 int launch_gcn_forward_graph(int F, int A, const float* x, int num_nodes, const int32_t* csr_ptr, const int32_t* csr_src,
                              const float* csr_w, const int32_t* graph_ptr, int num_graphs, const float* packed,
                              float* work0, float* work1, float* pooled, float* logits, float* policy, float* value_pre,

@@ -1369,7 +1369,8 @@ __global__ __launch_bounds__(64 * HEADS_WAVES, 4) void gcn_heads_mm_kernel(float
 template <int TRACK>
 __global__ __launch_bounds__(64 * NWV, 4) void gcn_trunk_boards_mm_kernel(const void* __restrict__ states, int fmt, int B, const float* __restrict__ pk,
                                                                           float* __restrict__ pooled, const uint8_t* __restrict__ active,
-                                                                          int phase_delay, int32_t* __restrict__ saturated) {
+                                                                          int phase_delay, int32_t* __restrict__ saturated,
+                                                                          const int32_t* __restrict__ list, const int32_t* __restrict__ list_count) {
     AQG_TRACE_BEGIN
     __shared__ TrunkSmemM sm;
     // The two workgroups resident on a CU run identical phase sequences; a start offset for the second-resident ones
@@ -1394,7 +1395,13 @@ __global__ __launch_bounds__(64 * NWV, 4) void gcn_trunk_boards_mm_kernel(const 
     const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int wave = wave0;
 
-    int b = blockIdx.x;
+    // `list` (optional): the launch's boards as a COMPACT list of indices, *list_count long -- workgroup w takes entries w, w + grid, ...
+    // The MCTS with its evaluation cache on hands over the ~quarter of a set's leaves that miss the cache this way: walking the
+    // mask instead, a workgroup's share of a 4,096-slot set is Binomial(8, 1/4) boards and the launch lasts as long as the
+    // unluckiest workgroup (38 us against ~22 for the same boards spread evenly).
+    int j = blockIdx.x;
+    const int nlist = list ? __builtin_amdgcn_readfirstlane(*list_count) : 0;
+    int b = list ? (j < nlist ? __builtin_amdgcn_readfirstlane(list[j]) : B) : (int)blockIdx.x;
     // A board's record lives in two VGPRs of EVERY wave (each wave fetches it itself: 24-72 bytes), one board ahead:
     //   fmt 0 (state72): rec0 = wall byte of slot `lane`, rec1 = header dword;  fmt 1 (QState): rec0 = dword `lane` (< 5)
     uint32_t rec0 = 0, rec1 = 0;
@@ -1413,7 +1420,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void gcn_trunk_boards_mm_kernel(const 
     // one behind the other (one memory latency off every launch -- the MCTS's launches are one board per workgroup, ~94 % active).
     if (b < B) {
         fetch_record(b, rec0, rec1);
-        if (active && !active[b]) {                   // (workgroup-uniform) inactive slot: walk on to the next active board
+        if (!list && active && !active[b]) {          // (workgroup-uniform) inactive slot: walk on to the next active board
             do { b += gridDim.x; } while (b < B && !active[b]);
             if (b < B) fetch_record(b, rec0, rec1);
         }
@@ -1455,8 +1462,9 @@ __global__ __launch_bounds__(64 * NWV, 4) void gcn_trunk_boards_mm_kernel(const 
         request_bias(out, rs, 0, toff, wave);                            // lands under the input build + barrier
         AQG_STAMP_AT(6)
         build_inputs(hw, vw, hd, 1);                                     // the layer-1 input rows G'
-        int bn = b + gridDim.x;
-        while (bn < B && active && !active[bn]) bn += gridDim.x;
+        int bn;
+        if (list) { j += gridDim.x; bn = j < nlist ? __builtin_amdgcn_readfirstlane(list[j]) : B; }
+        else { bn = b + gridDim.x; while (bn < B && active && !active[bn]) bn += gridDim.x; }
         AQG_BOARD_BARRIER();                     // this board's G' rows are complete; the previous board is done
         AQG_STAMP_AT(0)
         phase_prio(1);
@@ -1719,7 +1727,7 @@ int profile_collect(double* total_ms, long long* launches, long long* boards, in
 
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
-                              int flags, int32_t* saturated, hipStream_t st) {
+                              int flags, int32_t* saturated, hipStream_t st, const int32_t* list, const int32_t* list_count) {
     if (N != 9) return fail("fused board trunk is built for 9x9; use aqg_gcn_forward_graph for other sizes");
     if (B <= 0) return 0;
     if (!pooled) return fail("pooled workspace is required");
@@ -1739,11 +1747,12 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
         // SIMD to hide each other's vector work, the highest throughput at every launch size (tools/trunk_scan.py)
         int grid = B < 512 ? B : 512;
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
-        const int opts = (B >= g_trunk_delay_min_boards ? g_trunk_phase_delay : 0) | ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16);
+        const int opts = ((B >= g_trunk_delay_min_boards && !list) ? g_trunk_phase_delay : 0) |     // (a list is a fraction of B: no start offset)
+                         ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16);
         if ((flags & AQG_GNN_RANGE_PROVEN) && saturated)
-            hipLaunchKernelGGL(gcn_trunk_boards_mm_kernel<0>, dim3(grid), dim3(64 * NWV), 0, st, states, fmt, B, packed, pooled, active, opts, saturated);
+            hipLaunchKernelGGL(gcn_trunk_boards_mm_kernel<0>, dim3(grid), dim3(64 * NWV), 0, st, states, fmt, B, packed, pooled, active, opts, saturated, list, list_count);
         else
-            hipLaunchKernelGGL(gcn_trunk_boards_mm_kernel<2>, dim3(grid), dim3(64 * NWV), 0, st, states, fmt, B, packed, pooled, active, opts, saturated);
+            hipLaunchKernelGGL(gcn_trunk_boards_mm_kernel<2>, dim3(grid), dim3(64 * NWV), 0, st, states, fmt, B, packed, pooled, active, opts, saturated, list, list_count);
     }
     if (g_profile_trunk == 1) (void)hipEventRecord(prof_event(), st);
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;
@@ -1910,8 +1919,10 @@ size_t boards_any_workspace_floats(int N, int B) { return (size_t)B * N * N * 27
 
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
-                                  float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st) {
-    if (N == 9) return launch_gcn_forward_boards(N, states, fmt, B, packed, pooled, logits, policy, value_pre, value, active, flags, saturated, st);
+                                  float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st,
+                                  const int32_t* list, const int32_t* list_count) {
+    // (`list`: see gcn_trunk_boards_mm_kernel; honoured by the 9x9 split trunk only -- every other path walks the mask, which must agree)
+    if (N == 9) return launch_gcn_forward_boards(N, states, fmt, B, packed, pooled, logits, policy, value_pre, value, active, flags, saturated, st, list, list_count);
     if (!(N == 3 || N == 5 || N == 7)) return fail("board_size must be 3, 5, 7 or 9");
     if (B <= 0) return 0;
     if (!pooled) return fail("pooled workspace is required");

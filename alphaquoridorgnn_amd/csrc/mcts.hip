@@ -32,11 +32,11 @@ int launch_legal_actions(int N, const void* states, int fmt, int B, uint8_t* mas
                          const uint8_t* active, hipStream_t st);
 int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const float* packed, float* pooled,
                               float* logits, float* policy, float* value_pre, float* value, const uint8_t* active,
-                              int flags, int32_t* saturated, hipStream_t st);
+                              int flags, int32_t* saturated, hipStream_t st, const int32_t* list = nullptr, const int32_t* list_count = nullptr);
 size_t boards_any_workspace_floats(int N, int B);
 int launch_gcn_forward_boards_any(int N, const void* states, int fmt, int B, const float* packed, float* workspace,
                                   size_t workspace_floats, float* pooled, float* logits, float* policy, float* value_pre,
-                                  float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st);
+                                  float* value, const uint8_t* active, int flags, int32_t* saturated, hipStream_t st, const int32_t* list = nullptr, const int32_t* list_count = nullptr);
 extern int g_trunk_variant, g_trunk_grid, g_trunk_phase_delay, g_trunk_delay_min_boards, g_profile_trunk, g_trunk_prio, g_heads_prio;
 void profile_mark(hipStream_t st, long long units);
 int g_use_graph = 1;       // aqg_set_option("use_graph", 0) forces plain launches
@@ -198,6 +198,7 @@ __global__ void engine_set_roots_kernel(aqg_engine e, const uint8_t* __restrict_
 // ------------------------------------------------------------------------------------------------
 __global__ void engine_begin_move_kernel(aqg_engine e) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e.eval_count) for (int i = g; i <= e.sims; i += gridDim.x * blockDim.x) e.eval_count[i] = 0;      // evaluation cache: entries of each simulation's list
     if (g >= e.num_games || !e.game_active[g]) return;
     NodeRec root;
     root.w = 0.0; root.p = 0.f; root.n = 0; root.kids = 0; root.action = 0xFF; root.q = 0.f; root.cp = 0.f;
@@ -478,7 +479,7 @@ int g_step_fast_depth = 61;
 
 template <int N>
 __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int lane, int do_expand, int do_select, int fast_depth,
-                                               float* __restrict__ polbuf /* this wave's 256 floats of LDS */) {
+                                               float* __restrict__ polbuf /* this wave's 256 floats of LDS */, int list_sim) {
     constexpr int A = Geo<N>::A;
     NodeRec* __restrict__ nodes = game_nodes(e, g);
     int* path = e.path + (size_t)g * (e.sims + 2);
@@ -945,7 +946,12 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
                 e.legal_count[g] = total;
                 e.path_len[g] = depth;
                 e.leaf_flag[g] = 1;
-                if (cache_on) { e.eval_mask[g] = 1; e.eval_cache_slot[g] = newslot; }
+                if (cache_on) {
+                    e.eval_mask[g] = 1; e.eval_cache_slot[g] = newslot;
+                    // large sets: the leaves the network must evaluate, as a compact list for the trunk launch of this simulation (the
+                    // order of the entries is whatever order the waves arrive in -- every board's evaluation is independent of it)
+                    if (list_sim >= 0) e.eval_list[atomicAdd(e.eval_count + list_sim, 1)] = g;
+                }
             }
         }
     }
@@ -964,7 +970,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
 // step -> GNN trunk -> GNN heads (3 kernels instead of select / legal / trunk / heads / expand).
 // ------------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(512) void engine_step_fast_kernel(aqg_engine e, int do_expand, int do_select, int fast_depth) {
+__global__ __launch_bounds__(512) void engine_step_fast_kernel(aqg_engine e, int do_expand, int do_select, int fast_depth, int list_sim) {
     __shared__ float polbuf[8][256];
     AQG_TRACE_BEGIN
     const int lane = threadIdx.x & 63;
@@ -973,7 +979,7 @@ __global__ __launch_bounds__(512) void engine_step_fast_kernel(aqg_engine e, int
     // workgroup's vector work, finishes sooner and gives its CU's second trunk slot back sooner (option "step_prio")
     { const int pr = (fast_depth >> 8) & 3; if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 3) __builtin_amdgcn_s_setprio(3); }
     fast_depth &= 0xFF;
-    if (g < e.num_games) game_step_fast<N>(e, g, lane, do_expand, do_select, fast_depth, polbuf[threadIdx.x >> 6]);
+    if (g < e.num_games) game_step_fast<N>(e, g, lane, do_expand, do_select, fast_depth, polbuf[threadIdx.x >> 6], list_sim);
     AQG_TRACE_END(1, (unsigned long long)(uintptr_t)e.pooled)
 }
 AQG_TRACE_SETTER(set_trace_mcts)
@@ -1001,12 +1007,12 @@ __global__ __launch_bounds__(256) void engine_step_kernel(aqg_engine e, int do_e
 }
 
 template <int N>
-static void launch_step(const aqg_engine& e, int do_expand, int do_select, hipStream_t st) {
+static void launch_step(const aqg_engine& e, int do_expand, int do_select, hipStream_t st, int list_sim = -1) {
     const dim3 grid((e.num_games + 3) / 4), block(256);
     if (g_profile_trunk == 2) profile_mark(st, e.num_games);       // measurement mode 2: the event pairs bracket the step launches
     if (g_step_variant == 1) {
         const int wpb = (g_step_waves == 1 || g_step_waves == 2 || g_step_waves == 8) ? g_step_waves : 4;
-        hipLaunchKernelGGL(engine_step_fast_kernel<N>, dim3((e.num_games + wpb - 1) / wpb), dim3(64 * wpb), 0, st, e, do_expand, do_select, g_step_fast_depth | ((g_step_prio & 3) << 8));
+        hipLaunchKernelGGL(engine_step_fast_kernel<N>, dim3((e.num_games + wpb - 1) / wpb), dim3(64 * wpb), 0, st, e, do_expand, do_select, g_step_fast_depth | ((g_step_prio & 3) << 8), list_sim);
     }
     else hipLaunchKernelGGL(engine_step_kernel<N>, grid, block, 0, st, e, do_expand, do_select);
     if (g_profile_trunk == 2) profile_mark(st, -1);
@@ -1178,6 +1184,7 @@ static int validate(const aqg_engine& e) {
     if (e.eval_cache_keys) {
         if (e.prior_mode != 0) return fail("the evaluation cache serves the GNN evaluator only (prior_mode 0)");
         if (!e.eval_cache_rows || !e.eval_cache_slot || !e.eval_mask || !e.stat_cache_hits) return fail("eval_cache_rows / eval_cache_slot / eval_mask / stat_cache_hits are required with eval_cache_keys");
+        if ((e.eval_list == nullptr) != (e.eval_count == nullptr)) return fail("eval_list and eval_count come together");
         if (e.eval_cache_log2 < 6 || e.eval_cache_log2 > 20) return fail("eval_cache_log2 must be 6..20");
         if (g_step_variant != 1) return fail("the evaluation cache needs step_variant 1");
     }
@@ -1189,13 +1196,16 @@ static int enqueue_sims(const aqg_engine& e, hipStream_t st) {
     if (e.prior_mode == 2) return fail("prior_mode 2 (external evaluator): drive the move with aqg_engine_begin_move / _step / _finish_move");
     const dim3 grid((e.num_games + 3) / 4), block(256);
     hipLaunchKernelGGL(engine_begin_move_kernel, dim3((e.num_games + 255) / 256), dim3(256), 0, st, e);
+    // evaluation cache on a set larger than the trunk's grid: the leaves that miss the cache go to the trunk as a compact list
+    const bool use_list = e.eval_cache_keys && e.eval_list && N == 9 && e.num_games > 512 && g_trunk_variant >= 3 && g_step_variant == 1 && !(e.gnn_flags & AQG_GNN_EXACT_F32);
     for (int sim = 0; sim < e.sims; ++sim) {
-        launch_step<N>(e, sim > 0 ? 1 : 0, 1, st);
+        launch_step<N>(e, sim > 0 ? 1 : 0, 1, st, use_list ? sim : -1);
         if (e.prior_mode == 0) {
             // 9x9: the fused trunk; smaller boards: plain kernels over e.gnn_workspace
             if (int r = launch_gcn_forward_boards_any(N, e.leaf_state, 1, e.num_games, e.packed_weights, e.gnn_workspace,
                                                       e.gnn_workspace ? boards_any_workspace_floats(N, e.num_games) : 0, e.pooled, nullptr,
-                                                      e.policy, nullptr, e.value, e.eval_cache_keys ? e.eval_mask : e.leaf_flag, e.gnn_flags, e.counters + 5, st))
+                                                      e.policy, nullptr, e.value, e.eval_cache_keys ? e.eval_mask : e.leaf_flag, e.gnn_flags, e.counters + 5, st,
+                                                      use_list ? e.eval_list : nullptr, use_list ? e.eval_count + sim : nullptr))
                 return r;
         } else {
             hipLaunchKernelGGL(engine_fake_eval_kernel<N>, grid, block, 0, st, e);

@@ -104,6 +104,8 @@ class BatchedSelfPlay:
             t["eval_cache_slot"] = torch.full((G,), -1, dtype=torch.int32, device=dev)
             t["eval_mask"] = z((G,), torch.uint8)
             t["stat_cache_hits"] = z((G,), torch.int32)
+            t["eval_list"] = z((G,), torch.int32)
+            t["eval_count"] = z((self.sims + 1,), torch.int32)
 
         e = self.e = _lib.EngineStruct()
         e.board_size, e.num_walls, e.plies_for_draw = self.N, self.num_walls, self.plies_for_draw
@@ -121,7 +123,7 @@ class BatchedSelfPlay:
             setattr(e, name, t[name].data_ptr())
         e.gnn_workspace = t["gnn_workspace"].data_ptr() if "gnn_workspace" in t else None
         if self.eval_cache_slots:
-            for name in ("eval_cache_keys", "eval_cache_rows", "eval_cache_slot", "eval_mask", "stat_cache_hits"):
+            for name in ("eval_cache_keys", "eval_cache_rows", "eval_cache_slot", "eval_mask", "stat_cache_hits", "eval_list", "eval_count"):
                 setattr(e, name, t[name].data_ptr())
             e.eval_cache_log2 = self.eval_cache_slots.bit_length() - 1
         self.record_history = record_history

@@ -226,6 +226,9 @@ typedef struct aqg_engine {
     void* eval_cache_keys; void* eval_cache_rows;
     int32_t* eval_cache_slot /* [G] entry reserved for the pending evaluation, -1 none */; uint8_t* eval_mask /* [G] */;
     int32_t* stat_cache_hits /* [G] */;
+    /* optional (both or neither): for sets of more than 512 slots aqg_engine_move hands the leaves that miss the table to the trunk
+     * launch of simulation s as a compact list -- eval_list[0 .. eval_count[s]) -- instead of a mask to walk */
+    int32_t* eval_list /* [G] */; int32_t* eval_count /* [sims + 1] */;
     int32_t eval_cache_log2;
 } aqg_engine;
 

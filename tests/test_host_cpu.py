@@ -28,7 +28,7 @@ def test_capi_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} not bound in _lib.SIGNATURES"
     assert lib.aqg_abi_version() == _lib.ABI_VERSION
     assert lib.aqg_gcn_packed_floats(9) > 64082          # all 64,082 parameters + padding + fragment copies
-    assert ctypes.sizeof(_lib.EngineStruct) == 11 * 4 + 2 * 4 + 4 + 32 * 8 + 8   # 13 scalars (+4 pad) + 32 pointers (ABI 10: + 5 of the evaluation cache) + eval_cache_log2 (+4 pad)
+    assert ctypes.sizeof(_lib.EngineStruct) == 11 * 4 + 2 * 4 + 4 + 34 * 8 + 8   # 13 scalars (+4 pad) + 34 pointers (ABI 10: + 7 of the evaluation cache) + eval_cache_log2 (+4 pad)
     assert ctypes.sizeof(_lib.TrainStruct) == 8 * 4 + 4 * 14 * 8 + 17 * 8      # aqg_train: 8 scalars, 4 x 14 + 17 pointers
 
 
