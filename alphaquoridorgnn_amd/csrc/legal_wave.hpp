@@ -10,32 +10,51 @@
 
 namespace aqg {
 
-// mask: [A] u8 or nullptr; order: [MAX_LEGAL] u8 or nullptr (entries >= count are 0xFF).  Returns the count
-// (uniform across the wave).  All 64 lanes of the wave must call it.
+// Step 1 of legal_actions() for one state, separable from the searches: the open-edge boards and, per wall slot, geometric placement
+// and the reference's touch-count prefilter -- wave-uniform mask algebra, no memory access (the MCTS step kernel runs it in the shadow of
+// its evaluation-cache probe).  All 64 lanes of the wave must call it.
+struct LegalPrep {
+    Open base;
+    uint64_t pH, pV, nH, nV;      // placeable H / V slots; those that also need the two path searches
+    bool needH, needV;            // this lane's slot
+};
 template <int N>
-__device__ __forceinline__ int wave_legal_actions(const QState& s, int lane, uint8_t* __restrict__ mask,
-                                                  uint8_t* __restrict__ order) {
-    constexpr int V = Geo<N>::V, NW = Geo<N>::NW, A = Geo<N>::A;
+__device__ __forceinline__ LegalPrep wave_legal_prepare(const QState& s, int lane) {
+    constexpr int NW = Geo<N>::NW;
+    LegalPrep p;
     // The wall masks are the same in every lane: as wave-uniform scalars, the open-edge bitboards, the placement masks
     // and the touch-count prefilter of ALL slots are computed once per wave on the scalar unit; lanes only test bits.
     const uint64_t hw = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(s.hw >> 32)) << 32) |
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s.hw);
     const uint64_t vw = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(s.vw >> 32)) << 32) |
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s.vw);
-    const Open base = make_open<N>(hw, vw);
+    p.base = make_open<N>(hw, vw);
     // Step 1 (lane = wall slot): geometric placement and the touch-count prefilter.  A placeable candidate that
     // the prefilter clears is legal outright (game_logic.py:327-328); the others need the two path searches.
-    bool placeH = false, placeV = false, needH = false, needV = false;
+    bool placeH = false, placeV = false;
+    p.needH = false; p.needV = false;
     if (s.pwl > 0 && lane < NW) {
         uint64_t hp, vp, hb, vb;
         placeable_masks<N>(hw, vw, hp, vp);
         possibly_blocking_masks<N>(hw, vw, hb, vb);
         placeH = (hp >> lane) & 1;
         placeV = (vp >> lane) & 1;
-        needH = placeH && ((hb >> lane) & 1);
-        needV = placeV && ((vb >> lane) & 1);
+        p.needH = placeH && ((hb >> lane) & 1);
+        p.needV = placeV && ((vb >> lane) & 1);
     }
-    const uint64_t pH = __ballot(placeH), pV = __ballot(placeV), nH = __ballot(needH), nV = __ballot(needV);
+    p.pH = __ballot(placeH); p.pV = __ballot(placeV); p.nH = __ballot(p.needH); p.nV = __ballot(p.needV);
+    return p;
+}
+
+// mask: [A] u8 or nullptr; order: [MAX_LEGAL] u8 or nullptr (entries >= count are 0xFF).  Returns the count
+// (uniform across the wave).  All 64 lanes of the wave must call it.
+template <int N>
+__device__ __forceinline__ int wave_legal_finish(const QState& s, const LegalPrep& prep, int lane, uint8_t* __restrict__ mask,
+                                                 uint8_t* __restrict__ order) {
+    constexpr int V = Geo<N>::V, NW = Geo<N>::NW, A = Geo<N>::A;
+    const Open& base = prep.base;
+    const bool needH = prep.needH, needV = prep.needV;
+    const uint64_t pH = prep.pH, pV = prep.pV, nH = prep.nH, nV = prep.nV;
     // Step 2 (lane = task): the k-th candidate that needs the searches (H candidates in slot order, then V) goes to
     // lane k, which runs the mover's and the enemy's flood fill interleaved (can_reach2: two independent dependency
     // chains keep a lone wavefront's VALU busy; one fill per lane and twice the rounds measured slower).
@@ -100,6 +119,14 @@ __device__ __forceinline__ int wave_legal_actions(const QState& s, int lane, uin
         for (int i = total + lane; i < MAX_LEGAL; i += 64) order[i] = 0xFF;
     }
     return total;
+}
+
+
+template <int N>
+__device__ __forceinline__ int wave_legal_actions(const QState& s, int lane, uint8_t* __restrict__ mask,
+                                                  uint8_t* __restrict__ order) {
+    const LegalPrep prep = wave_legal_prepare<N>(s, lane);
+    return wave_legal_finish<N>(s, prep, lane, mask, order);
 }
 
 }  // namespace aqg

@@ -897,6 +897,8 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
         // evaluation that the next step's expansion will see.
         bool hit = false;
         int newslot = -1;
+        LegalPrep prep;
+        if (!cache_on) prep = wave_legal_prepare<N>(s, lane);
         if (cache_on) {
             const uint32_t misc = eval_cache_misc(s);
             uint64_t h = s.hw * 0x9E3779B97F4A7C15ull ^ s.vw * 0xC2B2AE3D27D4EB4Full ^ (uint64_t)misc * 0x165667B19E3779F9ull;
@@ -906,6 +908,9 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
             const u32x4* keys = reinterpret_cast<const u32x4*>(e.eval_cache_keys) + 2 * base;
             const uint32_t idx = (home + (uint32_t)lane) & cmask;
             const u32x4 k0 = keys[2 * idx], k1 = keys[2 * idx + 1];
+            // ... and while the probe is in flight: the part of legal_actions() that needs no memory (placement masks, touch-count
+            // prefilter: scalar mask algebra) -- a miss has it ready, a hit has lost nothing
+            prep = wave_legal_prepare<N>(s, lane);
             // (elements through scalars: __builtin_bit_cast / readlane of a vector ELEMENT expression reads element 0 with hipcc 7.2)
             const uint32_t a0 = k0[0], a1 = k0[1], a2 = k0[2], a3 = k0[3], b0 = k1[0], b1 = k1[1], b2 = k1[2], b3 = k1[3];
             const bool match = a0 == (uint32_t)s.hw && a1 == (uint32_t)(s.hw >> 32) && a2 == (uint32_t)s.vw && a3 == (uint32_t)(s.vw >> 32) &&
@@ -939,7 +944,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
             }
         }
         if (!hit) {
-            const int total = wave_legal_actions<N>(s, lane, nullptr, e.legal_order + (size_t)g * MAX_LEGAL);
+            const int total = wave_legal_finish<N>(s, prep, lane, nullptr, e.legal_order + (size_t)g * MAX_LEGAL);
             STEP_STAMP(3)
             if (lane == 0) {
                 store_state(e.leaf_state, g, s);

@@ -265,6 +265,8 @@ def main():
                     help="torch.distributed backend for N > 1: nccl = RCCL over xGMI (default); gloo = host tensors, for rehearsing "
                          "several ranks on one GPU")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the step-kernel / slot-refill / training legs (profiling runs)")
+    ap.add_argument("--eval-cache-slots", type=int, default=8192,
+                    help="entries per game slot of the evaluation cache in the `eval_cache` LEG (0 = skip the leg); the headline `value` always runs without it")
     ap.add_argument("--large-games", type=int, default=16384,
                     help="extra single-GPU leg: one generation at this many concurrent games (north star: >= 10k); 0 = skip")
     ap.add_argument("--rccl-child", default=None, choices=_RCCL_ORDERS, help="internal: one process of the rccl_group_alive leg")
@@ -540,6 +542,42 @@ def main():
         large = {"concurrent_games": args.large_games, "sims_per_move": args.sims, "games_per_s": c["finished"] / dt, "s_per_generation": dt,
                  "leaf_evals_per_s": c["leaf_evals"] / dt}
 
+    # ---- evaluation cache (include/aqgnn.h eval_cache_keys; engine.BatchedSelfPlay(eval_cache_slots=...)): the SAME generations with the
+    #      per-slot table of already-evaluated positions on.  Reported as a leg, never as `value`: the games and records are bit-identical
+    #      (checked here on a small generation, and in tests/test_gpu_parity.py against the oracle), the network simply is not asked twice.
+    cache_leg = None
+    if world == 1 and args.eval_cache_slots > 0 and not args.no_extra_legs:
+        del eng
+        torch.cuda.empty_cache()
+        small = {}
+        for slots in (0, 1024):
+            es = MultiSetSelfPlay(model, num_games=256, sims=50, num_sets=args.sets, seed=31, eval_cache_slots=slots)
+            cs = es.play_generation()
+            small[slots] = ([x.cpu() for x in es.history_tensors()], cs)
+            del es
+        identical = all(torch.equal(a, b) for a, b in zip(small[0][0], small[1024][0])) and small[0][1]["leaf_evals"] == small[1024][1]["leaf_evals"]
+        cache_leg = {"slots_per_game": args.eval_cache_slots, "bytes_per_slot": 736,
+                     "identity_check": {"games": 256, "sims": 50, "rows": int(small[0][0][0].shape[0]), "rows_identical_to_cache_off": bool(identical)}}
+        del small
+        for label, games, slots in (("headline_config", args.games, args.eval_cache_slots), ("large_batch", args.large_games, min(args.eval_cache_slots, 2048))):
+            if games <= 0:
+                continue
+            torch.cuda.empty_cache()
+            eng = MultiSetSelfPlay(model, num_games=games, sims=args.sims, num_sets=args.sets, seed=1000 if label == "headline_config" else 77, eval_cache_slots=slots)
+            for _ in range(2):
+                eng.move()
+            eng.sync()
+            torch.cuda.synchronize()
+            t1 = time.time()
+            c, _ = one_step(False)
+            torch.cuda.synchronize()
+            dt = time.time() - t1
+            cache_leg[label] = {"concurrent_games": games, "slots_per_game": slots, "games_per_s": c["finished"] / dt, "s_per_generation": dt,
+                                "leaf_evals_per_s": c["leaf_evals"] / dt, "hit_rate": c["cache_hits"] / max(c["leaf_evals"], 1),
+                                "network_evals_per_s": (c["leaf_evals"] - c["cache_hits"]) / dt}
+            del eng
+        torch.cuda.empty_cache()
+
     if rank == 0:
         achieved = trunk_boards * TRUNK_FLOP_PER_BOARD / (trunk_ms * 1e-3) if trunk_ms > 0 else 0.0   # rank 0's sampled launches
         boards_per_s_kernel = trunk_boards / (trunk_ms * 1e-3) if trunk_ms > 0 else 0.0
@@ -593,6 +631,12 @@ def main():
         }
         if rccl_leg is not None:
             out["rccl_group_alive"] = rccl_leg
+        if cache_leg is not None:
+            for k in ("headline_config", "large_batch"):
+                if k in cache_leg:
+                    base = out["value"] if k == "headline_config" else (large or {}).get("games_per_s")
+                    cache_leg[k]["ratio_to_cache_off"] = cache_leg[k]["games_per_s"] / base if base else None
+            out["eval_cache"] = cache_leg
         legal_sample = legal_leg.pop("_sample", None) if legal_leg is not None else None
         if legal_leg is not None:
             out["legal_mask"] = legal_leg
