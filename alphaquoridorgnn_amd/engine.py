@@ -20,13 +20,14 @@ from .constants import BOARD_SIZE, board_params
 
 class BatchedSelfPlay:
     def __init__(self, model=None, num_games=2048, sims=50, board_size=BOARD_SIZE, device=None, temperature=1.0,
-                 c_puct=1.25, evaluator="gnn", fake_bias=0, seed=0, record_history=True, quota=None, eval_cache_slots=0):
+                 c_puct=1.25, evaluator="gnn", fake_bias=0, seed=0, record_history=True, quota=None, eval_cache_slots=None):
         """model: GraphPolicyValueNetwork/GNNNetwork (evaluator='gnn'); evaluator='fake' runs the integer-hash
         evaluator used by the parity tests (oracle/mcts.py FakeModel); evaluator='external' calls `model.predict(state,
         device)` -- ANY object honouring the reference's BaseNetwork contract (BaseNetwork.py:36-40), e.g. a stock CNN --
         once per simulation and game from the host, exactly like pv_mcts.py:47 (plumbing path: one host round trip per
         simulation).
-        eval_cache_slots (evaluator='gnn' only; a power of two >= 64, 0 = off): entries per game slot of the evaluation cache
+        eval_cache_slots (evaluator='gnn' only; a power of two >= 64, 0 = off; None = the environment's AQG_EVAL_CACHE_SLOTS, else
+        off): entries per game slot of the evaluation cache
         (include/aqgnn.h, `eval_cache_keys`): a leaf whose position this slot has already sent through the network is expanded from
         the stored priors / value / legal list -- bit-identical searches and game records, fewer network evaluations (736 bytes of
         HBM per entry)."""
@@ -93,6 +94,8 @@ class BatchedSelfPlay:
             t["packed_weights"] = z((4,), torch.float32)
             self._gnn_flags = 0
 
+        if eval_cache_slots is None:              # opt-in for whole programs (self_play, train_cycle, pv_mcts): one environment variable
+            eval_cache_slots = int(os.environ.get("AQG_EVAL_CACHE_SLOTS", "0")) if evaluator == "gnn" else 0
         self.eval_cache_slots = int(eval_cache_slots)
         if self.eval_cache_slots:
             if evaluator != "gnn":
@@ -140,10 +143,13 @@ class BatchedSelfPlay:
 
     def refresh_weights(self):
         if self.evaluator == "gnn":
-            self.t["packed_weights"] = self.model.packed_weights(self.dev)
-            self.e.packed_weights = self.t["packed_weights"].data_ptr()
-            self.e.gnn_flags = int(self.model.gnn_flags(self.dev))
-            if self.eval_cache_slots:      # the table holds the OLD weights' outputs
+            new = self.model.packed_weights(self.dev)        # the SAME tensor object while no parameter has changed
+            flags = int(self.model.gnn_flags(self.dev))
+            changed = new is not self.t["packed_weights"] or flags != int(self.e.gnn_flags)
+            self.t["packed_weights"] = new
+            self.e.packed_weights = new.data_ptr()
+            self.e.gnn_flags = flags
+            if self.eval_cache_slots and changed:      # the table holds the OLD weights' (or the other kernel build's) outputs
                 _lib.check(self.lib.aqg_engine_clear_eval_cache(ctypes.byref(self.e), self._stream()), "aqg_engine_clear_eval_cache")
 
     def move(self, uniforms=None):

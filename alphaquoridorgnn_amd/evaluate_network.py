@@ -64,8 +64,9 @@ class BatchedMatch:
             if g == 0:
                 self.engines.append(None)
                 continue
+            # (no evaluation cache here: the two players' weights take turns on one engine, a table would mix their outputs)
             kw = dict(num_games=g, sims=sims, board_size=board_size, temperature=temperature, seed=2 * int(seed) + first,
-                      device=device)
+                      device=device, eval_cache_slots=0)
             if evaluator == "gnn":
                 eng = BatchedSelfPlay(players[first], **kw)
             else:

@@ -1869,6 +1869,42 @@ def test_eval_cache_refill_weights_and_range_guard(dev):
         BatchedSelfPlay(model4, num_games=2, sims=4, eval_cache_slots=100)
 
 
+def test_eval_cache_through_the_program_surface(dev, tmp_path, monkeypatch):
+    """AQG_EVAL_CACHE_SLOTS switches the table on for whole programs: self_play() writes the same rows, and pv_mcts_policy -- whose
+    engine is kept between calls, so that the table carries the previous moves' evaluations into the next search, the tree reuse the
+    reference does not have (pv_mcts.py:84) -- returns the same policies along a game, while evaluate_network's match engines (two
+    weight sets taking turns on one engine) stay without a table."""
+    from alphaquoridorgnn_amd import self_play as sp, pv_mcts
+    from alphaquoridorgnn_amd.evaluate_network import BatchedMatch
+    from alphaquoridorgnn_amd.game_logic import State
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(pv_mcts, "PV_EVALUATE_COUNT", 12)
+    monkeypatch.setattr(sp, "write_data", lambda h: h)
+    model, _ = _model(1)
+
+    def walk():
+        pv_mcts._engines.clear()
+        st, out = State(), []
+        for _ in range(6):
+            pol = pv_mcts.pv_mcts_policy(model, st, 1.0)
+            out.append(list(pol))
+            st = st.next(st.legal_actions()[int(np.argmax(pol))])
+        eng = next(iter(pv_mcts._engines.values()))
+        return out, eng
+
+    rows0 = sp.self_play(model, games=6, seed=5)
+    pol0, eng0 = walk()
+    assert eng0.eval_cache_slots == 0
+    monkeypatch.setenv("AQG_EVAL_CACHE_SLOTS", "256")
+    rows1 = sp.self_play(model, games=6, seed=5)
+    pol1, eng1 = walk()
+    assert rows0 == rows1 and pol0 == pol1
+    assert eng1.eval_cache_slots == 256 and eng1.counters()["cache_hits"] > 0      # later searches found the earlier ones' positions
+    m2, _ = _model(2)
+    bm = BatchedMatch([model, m2], num_games=4, sims=6)
+    assert all(e is None or e.eval_cache_slots == 0 for e in bm.engines)
+
+
 def test_graft_entry_smoke():
     """The driver's smoke step (legal mask, GNN forward, MCTS, a tiny generation against the oracle) stays runnable."""
     import __graft_entry__
