@@ -32,6 +32,10 @@ it is measured and what bounds it is written HERE and in DESIGN.md section 5 (`n
                  the trunk launches of sampled moves -- one game set running alone, plain launches --, on the launch stream), against the matrix-pipe roof of the
                  fp32-equivalent fp16-split algorithm; the SURVEY 8(d) HBM figure (169,760 B/board against 8 TB/s) is
                  reported beside it as hbm_frac_survey_formula
+  eval_cache   : round 4 -- the evaluation cache (include/aqgnn.h eval_cache_keys): a small generation with the table off
+                 and on compared byte for byte in this process (identity_check), then the headline configuration and the large_batch
+                 configuration WITH the table, with hit rate, network evaluations/s and the ratio to the cache-less number of the same
+                 run.  `value` itself never uses the table.
   cpu_baseline : the oracle (CPU restatement, kind "port") on a bounded sample of the same workload -- one sequential self-play
                  loop per host core of the box's share (16), rates summed --, rank 0, N=1.
 """
