@@ -190,7 +190,7 @@ typedef struct aqg_engine {
     void* node_rec;
     /* per game, [G] */
     int32_t* node_count; uint8_t* root_state /* [G,24] */; int32_t* path /* [G, sims+2] */; int32_t* path_len;
-    uint8_t* leaf_flag /* [G] 1 = this simulation's leaf needs an evaluation */; uint8_t* leaf_state /* [G,24] */;
+    uint8_t* leaf_flag /* [G] 1 = this simulation's leaf needs an evaluation, 2 = it was served from the evaluation cache (below), 0 = no leaf (terminal / idle) */; uint8_t* leaf_state /* [G,24] */;
     uint8_t* game_active /* [G] slot is playing */; int32_t* slot_game /* [G] index of the game the slot is playing, -1 = retired */;
     /* per game, [quota] */
     int32_t* game_plies /* rows recorded */; int8_t* game_result /* z of ply 0 */; uint8_t* game_done /* 1 = finished */;
