@@ -458,8 +458,8 @@ __device__ __forceinline__ void game_expand_backup(const aqg_engine& e, int g, i
 // Diagnostic build only (-DAQG_STAMP, tools/stamp_step.py; never shipped): lane 0 of every game adds the cycles spent in each
 // phase of the step to pooled[g][2 i .. 2 i + 1] as u64 (the fake-evaluator runs the tool uses never touch `pooled`).
 #ifdef AQG_STAMP
-#define STEP_STAMP_DECL unsigned long long sp_prev = __builtin_readcyclecounter();
-#define STEP_STAMP(i) { const unsigned long long sp_now = __builtin_readcyclecounter(); if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[i] += sp_now - sp_prev; sp_prev = sp_now; }
+#define STEP_STAMP_DECL unsigned long long sp_prev = __builtin_readcyclecounter(), sp_loc[5] = {0, 0, 0, 0, 0};
+#define STEP_STAMP(i) { const unsigned long long sp_now = __builtin_readcyclecounter(); if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[i] += sp_now - sp_prev; sp_loc[i] = sp_now - sp_prev; sp_prev = sp_now; }
 #define LEVEL_STAMP(i) { const unsigned long long lv_now = __builtin_readcyclecounter(); if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[i] += lv_now - lv_prev; lv_prev = lv_now; }
 #else
 #define STEP_STAMP_DECL
@@ -963,7 +963,16 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
 #ifdef AQG_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STEP_STAMP(4)
-    if (lane == 0) reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128)[7] += 1;         // steps
+    if (lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(e.pooled + (size_t)g * 128);
+        o[7] += 1;                                                                                    // steps
+        // the tail: this game's LONGEST step (a launch lasts as long as the slowest game of its set) with its phases and depth, and a
+        // histogram of step lengths in 2,048-cycle buckets
+        const unsigned long long tot = sp_loc[0] + sp_loc[1] + sp_loc[2] + sp_loc[3] + sp_loc[4];
+        if (tot > o[16]) { o[16] = tot; for (int i = 0; i < 5; ++i) o[17 + i] = sp_loc[i]; o[22] = (unsigned long long)depth; o[23] = (unsigned long long)terminal; }
+        const unsigned long long bk = tot >> 11;
+        o[24 + (bk < 39 ? bk : 39)] += 1;
+    }
 #endif
 }
 

@@ -24,7 +24,8 @@ for warm_moves, moves in ((0, 4), (20, 4), (60, 4)):
     for _ in range(moves):
         eng.move()
     torch.cuda.synchronize()
-    raw = eng.t["pooled"].view(torch.int64).view(512, 64)[:, :12].double().cpu()
+    full = eng.t["pooled"].view(torch.int64).view(512, 64).double().cpu()
+    raw = full[:, :12]
     steps = raw[:, 7].sum().item()
     names = ["round-1 loads landed", "expand + old backup (issue)", "descent (all levels)", "legal actions of the leaf", "tail stores landed"]
     tot = raw[:, :5].sum().item()
@@ -34,3 +35,14 @@ for warm_moves, moves in ((0, 4), (20, 4), (60, 4)):
     lv = raw[:, 6].sum().item()                      # levels descended (the root level is not stamped: its children came with round 1)
     for i, n in () if not os.environ.get("AQG_LEVELS") else ((11, "chosen -> next request"), (8, "request -> state advanced"), (9, "... -> children arrived"), (10, "... -> child chosen")):
         print(f"      per level below the root: {n:28s} {raw[:, i].sum().item() / max(lv, 1):7.0f} cycles")
+
+    if os.environ.get("AQG_TAIL"):
+        mx = full[:, 16]
+        order = torch.argsort(mx, descending=True)[:16]
+        print(f"   longest step per game: median {mx.median().item():.0f}, max {mx.max().item():.0f} cycles; the 16 slowest games' longest steps, mean per phase:")
+        for i, n in enumerate(names):
+            print(f"      {n:30s} {full[order, 17 + i].mean().item():9.0f}")
+        print(f"      depth {full[order, 22].mean().item():.1f}, terminal {full[order, 23].mean().item():.2f}")
+        hist = full[:, 24:64].sum(0)
+        cum = torch.cumsum(hist, 0) / hist.sum()
+        print("   step length histogram (2,048-cycle buckets; share of steps at or below): " + " ".join(f"{(b + 1) * 2}k:{cum[b].item():.3f}" for b in range(4, 24)))
