@@ -38,7 +38,15 @@ def measure(tag, model):
 
 
 t0 = time.time()
+if os.environ.get("MODEL_PATH") and os.path.exists(os.environ["MODEL_PATH"]):      # measure a saved network only (A/B of library builds)
+    m = GNNNetwork()
+    m.prep_for_inference(os.environ["MODEL_PATH"])
+    measure("saved network  ", m)
+    sys.exit(0)
 print("PROMOTED", tc.train_cycle(num_cycles=CYCLES), f"({time.time() - t0:.0f} s)", flush=True)
+if os.environ.get("SAVE_LATEST"):
+    import shutil
+    shutil.copy(constants.PV_NETWORK_PATH + "latest.pth", os.environ["SAVE_LATEST"])
 rand = GNNNetwork().to(dev).eval()
 torch.manual_seed(0)
 measure("random weights ", GNNNetwork().to(dev).eval())
