@@ -1366,11 +1366,13 @@ __global__ __launch_bounds__(64 * HEADS_WAVES, 4) void gcn_heads_mm_kernel(float
 // pre-clamp outputs by a float maximum; the linear maps' outputs U (which are split themselves) by a float maximum of |U| against the
 // thresholds of PackedLayout::GUARD -- layer 2's aggregate is then below 65504 by  |V| <= 2.0625 max|U| + max|TB|,  layer 3's is not
 // split at all (the heads check the pooled row): one vector instruction per TWO values at three places.
-template <int TRACK>
+// LIST: the boards come as a compact list (below); the mask-walking instantiation carries none of that code
+template <int TRACK, bool LIST>
 __global__ __launch_bounds__(64 * NWV, 4) void gcn_trunk_boards_mm_kernel(const void* __restrict__ states, int fmt, int B, const float* __restrict__ pk,
                                                                           float* __restrict__ pooled, const uint8_t* __restrict__ active,
                                                                           int phase_delay, int32_t* __restrict__ saturated,
-                                                                          const int32_t* __restrict__ list, const int32_t* __restrict__ list_count) {
+                                                                          const int32_t* __restrict__ list_arg, const int32_t* __restrict__ list_count) {
+    const int32_t* __restrict__ const list = LIST ? list_arg : nullptr;
     AQG_TRACE_BEGIN
     __shared__ TrunkSmemM sm;
     // The two workgroups resident on a CU run identical phase sequences; a start offset for the second-resident ones
@@ -1749,10 +1751,14 @@ int launch_gcn_forward_boards(int N, const void* states, int fmt, int B, const f
         if (g_trunk_grid > 0 && g_trunk_grid < grid) grid = g_trunk_grid;
         const int opts = ((B >= g_trunk_delay_min_boards && !list) ? g_trunk_phase_delay : 0) |     // (a list is a fraction of B: no start offset)
                          ((g_trunk_prio >= 0 ? g_trunk_prio : (B >= 1024 ? 8 : 0)) << 16);
-        if ((flags & AQG_GNN_RANGE_PROVEN) && saturated)
-            hipLaunchKernelGGL(gcn_trunk_boards_mm_kernel<0>, dim3(grid), dim3(64 * NWV), 0, st, states, fmt, B, packed, pooled, active, opts, saturated, list, list_count);
-        else
-            hipLaunchKernelGGL(gcn_trunk_boards_mm_kernel<2>, dim3(grid), dim3(64 * NWV), 0, st, states, fmt, B, packed, pooled, active, opts, saturated, list, list_count);
+        const dim3 tg(grid), tb(64 * NWV);
+        if ((flags & AQG_GNN_RANGE_PROVEN) && saturated) {
+            if (list) hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<0, true>), tg, tb, 0, st, states, fmt, B, packed, pooled, active, opts, saturated, list, list_count);
+            else hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<0, false>), tg, tb, 0, st, states, fmt, B, packed, pooled, active, opts, saturated, list, list_count);
+        } else {
+            if (list) hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, true>), tg, tb, 0, st, states, fmt, B, packed, pooled, active, opts, saturated, list, list_count);
+            else hipLaunchKernelGGL((gcn_trunk_boards_mm_kernel<2, false>), tg, tb, 0, st, states, fmt, B, packed, pooled, active, opts, saturated, list, list_count);
+        }
     }
     if (g_profile_trunk == 1) (void)hipEventRecord(prof_event(), st);
     if (int r = check_launch("gcn_trunk_boards_kernel")) return r;

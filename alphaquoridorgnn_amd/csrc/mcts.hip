@@ -477,7 +477,8 @@ int g_step_waves = 8;              // games (wavefronts) per workgroup of the fa
 int g_step_variant = 1;
 int g_step_fast_depth = 61;
 
-template <int N>
+// CACHE: the evaluation cache's code is compiled in (its own kernel instantiation: the cache-less kernel carries none of it)
+template <int N, bool CACHE>
 __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int lane, int do_expand, int do_select, int fast_depth,
                                                float* __restrict__ polbuf /* this wave's 256 floats of LDS */, int list_sim) {
     constexpr int A = Geo<N>::A;
@@ -495,7 +496,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
     int pnode = 0;
     float polr[4] = {0.f, 0.f, 0.f, 0.f};
     // evaluation cache (aqgnn.h, ABI 10): a per-slot table of the positions this slot's games have already sent through the network
-    const bool cache_on = e.eval_cache_keys != nullptr && e.prior_mode == 0;
+    constexpr bool cache_on = CACHE;
     int cslot = -1;
     QState leaf_prev = s_loaded;      // the previous simulation's leaf (its key, when its evaluation goes into the table)
     if (do_expand) {
@@ -983,7 +984,7 @@ __device__ __forceinline__ void game_step_fast(const aqg_engine& e, int g, int l
 // a workgroup-scope fence is all the ordering needed.  Per simulation the engine then launches
 // step -> GNN trunk -> GNN heads (3 kernels instead of select / legal / trunk / heads / expand).
 // ------------------------------------------------------------------------------------------------
-template <int N>
+template <int N, bool CACHE>
 __global__ __launch_bounds__(512) void engine_step_fast_kernel(aqg_engine e, int do_expand, int do_select, int fast_depth, int list_sim) {
     __shared__ float polbuf[8][256];
     AQG_TRACE_BEGIN
@@ -993,7 +994,7 @@ __global__ __launch_bounds__(512) void engine_step_fast_kernel(aqg_engine e, int
     // workgroup's vector work, finishes sooner and gives its CU's second trunk slot back sooner (option "step_prio")
     { const int pr = (fast_depth >> 8) & 3; if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 3) __builtin_amdgcn_s_setprio(3); }
     fast_depth &= 0xFF;
-    if (g < e.num_games) game_step_fast<N>(e, g, lane, do_expand, do_select, fast_depth, polbuf[threadIdx.x >> 6], list_sim);
+    if (g < e.num_games) game_step_fast<N, CACHE>(e, g, lane, do_expand, do_select, fast_depth, polbuf[threadIdx.x >> 6], list_sim);
     AQG_TRACE_END(1, (unsigned long long)(uintptr_t)e.pooled)
 }
 AQG_TRACE_SETTER(set_trace_mcts)
@@ -1026,7 +1027,10 @@ static void launch_step(const aqg_engine& e, int do_expand, int do_select, hipSt
     if (g_profile_trunk == 2) profile_mark(st, e.num_games);       // measurement mode 2: the event pairs bracket the step launches
     if (g_step_variant == 1) {
         const int wpb = (g_step_waves == 1 || g_step_waves == 2 || g_step_waves == 8) ? g_step_waves : 4;
-        hipLaunchKernelGGL(engine_step_fast_kernel<N>, dim3((e.num_games + wpb - 1) / wpb), dim3(64 * wpb), 0, st, e, do_expand, do_select, g_step_fast_depth | ((g_step_prio & 3) << 8), list_sim);
+        const int fd = g_step_fast_depth | ((g_step_prio & 3) << 8);
+        const dim3 sg((e.num_games + wpb - 1) / wpb), sb(64 * wpb);
+        if (e.eval_cache_keys && e.prior_mode == 0) hipLaunchKernelGGL((engine_step_fast_kernel<N, true>), sg, sb, 0, st, e, do_expand, do_select, fd, list_sim);
+        else hipLaunchKernelGGL((engine_step_fast_kernel<N, false>), sg, sb, 0, st, e, do_expand, do_select, fd, -1);
     }
     else hipLaunchKernelGGL(engine_step_kernel<N>, grid, block, 0, st, e, do_expand, do_select);
     if (g_profile_trunk == 2) profile_mark(st, -1);

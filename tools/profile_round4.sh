@@ -22,14 +22,14 @@ if [ "$STAGE" = all ] || [ "$STAGE" = pmc ]; then
   : > $OUT/pmc_summary.csv
   for B in 480 65536; do
     export AQG_B=$B AQG_VARIANT=3 AQG_ITERS=5
-    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0>" prof_trunk.py "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU"
-    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0>" prof_trunk.py "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"
-    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0>" prof_trunk.py "GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES"
-    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0>" prof_trunk.py "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY"
-    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0>" prof_trunk.py "TCC_HIT_sum TCC_MISS_sum"
-    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0>" prof_trunk.py "FETCH_SIZE"
-    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0>" prof_trunk.py "WRITE_SIZE"
-    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0>" prof_trunk.py "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"
+    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0, false>" prof_trunk.py "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU"
+    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0, false>" prof_trunk.py "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"
+    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0, false>" prof_trunk.py "GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES"
+    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0, false>" prof_trunk.py "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY"
+    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0, false>" prof_trunk.py "TCC_HIT_sum TCC_MISS_sum"
+    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0, false>" prof_trunk.py "FETCH_SIZE"
+    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0, false>" prof_trunk.py "WRITE_SIZE"
+    run_pmc trunk_B$B "gcn_trunk_boards_mm_kernel<0, false>" prof_trunk.py "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"
   done
   for B in 4096 65536; do
     export AQG_B=$B AQG_ITERS=5
