@@ -563,10 +563,13 @@ def main():
         cache_leg = {"slots_per_game": args.eval_cache_slots, "bytes_per_slot": 736,
                      "identity_check": {"games": 256, "sims": 50, "rows": int(small[0][0][0].shape[0]), "rows_identical_to_cache_off": bool(identical)}}
         del small
-        for label, games, slots in (("headline_config", args.games, args.eval_cache_slots), ("large_batch", args.large_games, min(args.eval_cache_slots, 2048))):
+        for label, games, slots in (("headline_config", args.games, args.eval_cache_slots), ("large_batch", args.large_games, args.eval_cache_slots)):
             if games <= 0:
                 continue
             torch.cuda.empty_cache()
+            free = torch.cuda.mem_get_info(dev)[0]
+            while slots > 64 and games * slots * 736 > 0.5 * free:      # the table may take half of the free HBM (16,384 games x 8,192 entries = 99 GB of 288)
+                slots //= 2
             eng = MultiSetSelfPlay(model, num_games=games, sims=args.sims, num_sets=args.sets, seed=1000 if label == "headline_config" else 77, eval_cache_slots=slots)
             for _ in range(2):
                 eng.move()
